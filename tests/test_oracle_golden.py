@@ -1,0 +1,142 @@
+"""CPU: the oracle restatement against the fixtures the REFERENCE produced (tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pix4point_oracle as O
+
+FPS_TAGS = ['n64', 'n100', 'n1024', 'n2048', 'n8192', 'dup1024']
+KNN_TAGS = ['n256k16', 'n1024k16', 'n1024k32', 'n2048k16']
+
+
+@pytest.fixture(scope='module')
+def fps(golden_dir):
+    return np.load(os.path.join(golden_dir, 'fps.npz'))
+
+
+@pytest.mark.parametrize('tag', FPS_TAGS)
+def test_fps_torch_restatement_matches_reference(fps, tag):
+    pts = torch.from_numpy(fps[f'{tag}_points'])
+    start = torch.from_numpy(fps[f'{tag}_start'])
+    want = fps[f'{tag}_idx'].astype(np.int64)
+    got = O.farthest_point_sampling(pts, pts.shape[1] // 4, start)
+    assert got.dtype == torch.int64
+    assert np.array_equal(got.numpy(), want)
+
+
+@pytest.mark.parametrize('tag', ['n64', 'n100', 'n1024', 'dup1024', 'n2048'])
+def test_fps_explicit_op_order_and_tie_rule(fps, tag):
+    """Pins what the HIP kernel implements: (dx*dx+dy*dy)+dz*dz unfused, lowest index on ties."""
+    pts = fps[f'{tag}_points']
+    got = O.fps_explicit_numpy(pts, pts.shape[1] // 4, fps[f'{tag}_start'])
+    assert np.array_equal(got, fps[f'{tag}_idx'].astype(np.int64))
+
+
+def test_fps_more_samples_than_points():
+    pts = O.synthetic_clouds(2, 16, seed=1)
+    got = O.farthest_point_sampling(pts, 64, torch.tensor([3, 5]))
+    assert got.shape == (2, 16)
+    assert all(sorted(r.tolist()) == list(range(16)) for r in got)
+
+
+@pytest.mark.parametrize('tag', KNN_TAGS)
+def test_knn_exact_policy_vs_reference_cdist(golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, 'knn.npz'))
+    pts = torch.from_numpy(z[f'{tag}_points'])
+    cidx = torch.from_numpy(z[f'{tag}_cidx'].astype(np.int64))
+    ref = z[f'{tag}_ref_idx'].astype(np.int32)
+    k = ref.shape[-1]
+    cen = torch.gather(pts, 1, cidx.unsqueeze(-1).expand(-1, -1, 3))
+    got = O.knn_indices(cen, pts, k).numpy()
+    assert got.dtype == np.int32
+    # rows whose neighbour distances are separated by more than cdist's matmul rounding must
+    # agree exactly; the rest must at least be the same SET up to the boundary element
+    gap = z[f'{tag}_min_gap']
+    clear = gap > 2e-6
+    assert clear.mean() > 0.9
+    assert np.array_equal(got[clear], ref[clear])
+    frac_equal = (got == ref).mean()
+    assert frac_equal > 0.999, frac_equal
+    # first neighbour of a centroid is the centroid's own point (distance exactly 0)
+    assert np.array_equal(got[..., 0], z[f'{tag}_cidx'])
+
+
+def test_knn_ties_go_to_lowest_index():
+    pts = torch.zeros(1, 8, 3)
+    pts[0, :, 0] = torch.tensor([0., 1., -1., 1., 2., -2., 0., 3.])
+    cen = pts[:, :1]
+    got = O.knn_indices(cen, pts, 6)[0, 0].tolist()
+    assert got == [0, 6, 1, 2, 3, 4]
+
+
+@pytest.mark.parametrize('tag', ['b2n256', 'b3n512'])
+def test_p3embed_restatement_matches_reference(golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, 'p3embed.npz'))
+    B, N, k, s_w, s_p, s_g = z[f'{tag}_meta'].tolist()
+    m = O.P3Embed(in_channels=3, k=k)
+    sd = O.seeded_state_dict(m, seed=s_w)
+    chk = float(sum(v.double().abs().sum() for v in sd.values() if v.is_floating_point()))
+    assert abs(chk - z[f'{tag}_weight_checksum'][0]) < 1e-6 * chk, 'seeded weights drifted'
+    m.load_state_dict(sd)
+    pts = O.synthetic_clouds(B, N, seed=s_p)
+    start = torch.arange(B) * 3
+    f = pts.clone().transpose(1, 2).contiguous()
+    m.eval()
+    with torch.no_grad():
+        p_list, f_list = m(pts, f, start)
+    assert np.array_equal(p_list[-1].numpy(), z[f'{tag}_centroids'])
+    np.testing.assert_allclose(f_list[-1].numpy(), z[f'{tag}_eval_tokens'], rtol=1e-5, atol=1e-5)
+    m.train()
+    p_list, f_list = m(pts, f, start)
+    tok = f_list[-1]
+    np.testing.assert_allclose(tok.detach().numpy(), z[f'{tag}_train_tokens'], rtol=1e-4, atol=1e-4)
+    (tok * torch.from_numpy(z[f'{tag}_train_gradw'])).sum().backward()
+    c1, c2 = m.convs[0][0], m.convs[0][1]
+    np.testing.assert_allclose(c1[0].weight.grad.numpy().reshape(256, 6), z[f'{tag}_g_conv1a'], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(c1[1].bias.grad.numpy(), z[f'{tag}_g_conv1b_bias'], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(c1[2].weight.grad.numpy(), z[f'{tag}_g_bn1_w'], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(c2[3].weight.grad.numpy().reshape(256, 512).sum(1), z[f'{tag}_g_conv2b_sum'], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(np.stack([c1[2].running_mean.numpy(), c1[2].running_var.numpy()]),
+                               z[f'{tag}_bn_running'], rtol=1e-4, atol=1e-5)
+
+
+def test_clshead_restatement_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'clshead.npz'))
+    head = O.ClsHead(in_channels=384, num_classes=40)
+    head.load_state_dict(O.seeded_state_dict(head, seed=400))
+    head.eval()
+    with torch.no_grad():
+        y = head(torch.from_numpy(z['x']))
+    np.testing.assert_allclose(y.numpy(), z['logits'], rtol=1e-5, atol=1e-6)
+
+
+def test_full_model_restatement_is_reproducible(golden_dir):
+    """Unpinned by the reference (timm absent): guards the oracle against accidental edits."""
+    z = np.load(os.path.join(golden_dir, 'full_tiny_restatement.npz'))
+    nc, D, L, H, s_w, s_p = z['meta'].tolist()
+    model = O.Pix4Point(num_classes=nc, embed_dim=D, depth=L, heads=H)
+    model.load_state_dict(O.seeded_state_dict(model, seed=s_w))
+    model.eval()
+    with torch.no_grad():
+        logits = model(torch.from_numpy(z['points']), torch.from_numpy(z['start']))
+    np.testing.assert_allclose(logits.numpy(), z['logits'], rtol=1e-4, atol=1e-5)
+
+
+def test_state_dict_names_match_reference_contract():
+    """key names a reference checkpoint carries."""
+    model = O.Pix4Point(num_classes=15, embed_dim=192, depth=2, heads=3)
+    keys = set(model.state_dict().keys())
+    for k in ['model.cls_token', 'model.cls_pos', 'model.patch_embed.convs.0.0.0.weight',
+              'model.patch_embed.convs.0.0.1.bias', 'model.patch_embed.convs.0.0.2.running_mean',
+              'model.patch_embed.convs.0.1.0.weight', 'model.patch_embed.convs.0.1.3.weight',
+              'model.patch_embed.convs.0.1.4.weight', 'model.proj.weight', 'model.pos_embed.0.weight',
+              'model.pos_embed.2.bias', 'model.vit.blocks.0.attn.qkv.weight',
+              'model.vit_blocks.1.mlp.fc2.bias', 'model.norm.weight', 'model.vit.norm.bias',
+              'model.vit.pos_embed', 'model.vit.patch_embed.proj.weight', 'model.vit.head.weight',
+              'cls_head.head.0.weight', 'cls_head.head.1.running_var', 'cls_head.head.8.bias']:
+        assert k in keys, k
+    assert model.state_dict()['model.patch_embed.convs.0.0.0.weight'].shape == (256, 6, 1, 1)
+    assert model.state_dict()['model.patch_embed.convs.0.1.0.weight'].shape == (512, 512, 1, 1)
+    assert model.state_dict()['model.patch_embed.convs.0.1.3.weight'].shape == (256, 512, 1, 1)
