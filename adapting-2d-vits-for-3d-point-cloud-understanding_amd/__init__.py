@@ -1,1 +1,7 @@
-X=1
+"""MI355X-native Pix4Point hot path (tokenizer + ViT encoder) behind the reference's Python API.
+
+The directory name follows the build contract and is not a Python identifier; import it with
+``importlib.import_module('adapting-2d-vits-for-3d-point-cloud-understanding_amd')`` or through the
+``p4p_amd`` alias module at the repository root.
+"""
+from . import _lib, ops  # noqa: F401

@@ -1,0 +1,420 @@
+// Flash-style multi-head self-attention (head_dim 64) forward + backward for gfx950.
+// Reference: timm Attention inside Block, restated in-repo at src/models/apf_utils.py:142-158
+// (qkv reshape (B,T,3,H,hd), softmax(q k^T * hd^-0.5) v, head merge), called from
+// src/models/pix4point.py:254-255.  The T x T score matrix never leaves registers.
+//
+// Layout: qkv is the fused projection output [B*T, 3*H*64] bf16 (q | k | v, head-major inside each),
+// out / dout are [B*T, H*64] bf16, lse2 / delta are [B,H,T] fp32.  lse2 = log2(sum exp(score)) in the
+// base-2 domain of c*score with c = scale*log2(e), so backward recomputes p = exp2(c*s - lse2).
+//
+// Work decomposition (all three kernels): workgroup = 4 waves; a wave owns 16 rows of the
+// "lane side" (queries in fwd/dQ, keys in dK/dV), the other side streams through LDS in 64-row
+// tiles filled by LDS-DMA (global_load_lds_dwordx4, double buffered, one barrier per tile).
+// Every tile is [64 rows][64 bf16] with 16-B chunk' = chunk ^ (row & 7): conflict-free both for
+// ds_read_b128 fragment reads and for ds_read_b64_tr_b16 transposing reads of 8 consecutive rows.
+//
+// MFMA plan (v_mfma_f32_16x16x32_bf16; lane l: g = l>>4, i = l&15):
+//   S^T[key][q]  = K . Q^T      A = K rows (b128 from LDS), B = Q^T (registers)      -> lane i = query
+//   O^T[d][q]   += V^T . P^T    A = V^T (tr read),         B = P^T = the S^T accumulators, packed
+// An accumulator tile (rows 16t+4g+r on the contraction side) is used directly as the next MFMA's B
+// operand; the A operand is fetched in the matching permuted k order: slot (g,j) of k-step s is
+// contraction row 32s + 16(j>>2) + 4g + (j&3), which is exactly what two tr reads of rows
+// 32s+4g.. and 32s+16+4g.. deliver.  No P/dS tile ever goes through LDS.
+#include "common.h"
+
+#define ATT_THREADS 256
+#define HD 64
+#define TILE_BYTES (64 * 128)
+
+struct AttnParams {
+    const __bf16* qkv;     // [B*T, 3D]
+    const __bf16* o;       // [B*T, D]   (bwd)
+    const __bf16* dout;    // [B*T, D]   (bwd)
+    __bf16* out;           // fwd: O [B*T, D]; bwd: dqkv [B*T, 3D]
+    float* lse2;           // [B,H,T]
+    float* delta;          // [B,H,T]
+    int B, T, H, D;
+    float scale;
+};
+
+// Stage 64 rows (row r of the tile = global row min(row0 + r, T-1) of sequence b) x 128 B.
+__device__ __forceinline__ void stage_rows(const __bf16* __restrict__ base, size_t ld, int row0, int T,
+                                           char* tile, int wave, int lane) {
+    const int rin = lane >> 3;
+    const int chunk = (lane & 7) ^ rin;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int piece = wave * 2 + q;
+        int r = row0 + piece * 8 + rin;
+        r = r < T ? r : T - 1;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(base + (size_t)r * ld + chunk * 8), LDS_PTR(tile + piece * 1024),
+                                         16, 0, 0);
+    }
+}
+
+// b128 fragment: rows r16*16 + i, contraction columns 32ks + 8g .. +7
+__device__ __forceinline__ bf16x8 frag_rows(const char* tile, int r16, int ks, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    return *reinterpret_cast<const bf16x8*>(tile + (r16 * 16 + i) * 128 + (((ks * 4 + g) ^ (i & 7)) << 4));
+}
+
+// transposed fragment: output index (lane side of the operand) = column 16*cb + i of the tile,
+// contraction slots (g,j) = rows 32s + 16(j>>2) + 4g + (j&3).
+__device__ __forceinline__ bf16x8 frag_tr(const char* tile, int s, int cb, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const int row = 32 * s + 4 * g + (i >> 2);
+    const int p = i & 3;
+    const int lchunk = 2 * cb + (p >> 1);
+    const char* a0 = tile + row * 128 + ((lchunk ^ (row & 7)) << 4) + (p & 1) * 8;
+    const int row1 = row + 16;
+    const char* a1 = tile + row1 * 128 + ((lchunk ^ (row1 & 7)) << 4) + (p & 1) * 8;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+__device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
+    bf16x8 r = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
+    return r;
+}
+
+__device__ __forceinline__ float xor_lanes_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16));
+    return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float xor_lanes_sum(float v) {
+    v += __shfl_xor(v, 16);
+    return v + __shfl_xor(v, 32);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * TILE_BYTES];     // [buf][K|V]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
+    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int T = p.T, D = p.D;
+    const size_t ld = (size_t)3 * D;
+    const __bf16* seq = p.qkv + (size_t)b * T * ld;
+    const __bf16* kbase = seq + D + h * HD;
+    const __bf16* vbase = seq + 2 * D + h * HD;
+    const float c = p.scale * 1.4426950408889634f;
+
+    const int q = qb * 64 + wave * 16 + i;
+    const int qc = q < T ? q : T - 1;
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+        qf[ks] = *reinterpret_cast<const bf16x8*>(seq + (size_t)qc * ld + h * HD + ks * 32 + g * 8);
+
+    f32x4 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, lsum = 0.f;
+
+    const int nkt = (T + 63) / 64;
+    stage_rows(kbase, ld, 0, T, lds, wave, lane);
+    stage_rows(vbase, ld, 0, T, lds + TILE_BYTES, wave, lane);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        const char* kt_lds = lds + (kt & 1) * 2 * TILE_BYTES;
+        const char* vt_lds = kt_lds + TILE_BYTES;
+        if (kt + 1 < nkt) {
+            char* nxt = lds + ((kt + 1) & 1) * 2 * TILE_BYTES;
+            stage_rows(kbase, ld, (kt + 1) * 64, T, nxt, wave, lane);
+            stage_rows(vbase, ld, (kt + 1) * 64, T, nxt + TILE_BYTES, wave, lane);
+        }
+        f32x4 s[4];
+#pragma unroll
+        for (int k16 = 0; k16 < 4; ++k16) {
+            s[k16] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                s[k16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(kt_lds, k16, ks, lane), qf[ks], s[k16], 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k16 = 0; k16 < 4; ++k16)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 64 + k16 * 16 + 4 * g + r;
+                s[k16][r] = key < T ? s[k16][r] * c : -INFINITY;
+                mx = fmaxf(mx, s[k16][r]);
+            }
+        mx = xor_lanes_max(mx);
+        const float mnew = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+        m = mnew;
+        float ps = 0.f;
+#pragma unroll
+        for (int k16 = 0; k16 < 4; ++k16)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[k16][r] = __builtin_amdgcn_exp2f(s[k16][r] - mnew);
+                ps += s[k16][r];
+            }
+        lsum = lsum * alpha + ps;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[d] *= alpha;
+        bf16x8 pb[2] = {pack_pair(s[0], s[1]), pack_pair(s[2], s[3])};
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss)
+                o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(vt_lds, ss, d, lane), pb[ss], o[d], 0, 0, 0);
+    }
+    const float l = xor_lanes_sum(lsum);
+    const float inv = 1.0f / l;
+    if (q < T) {
+        __bf16* dst = p.out + ((size_t)b * T + q) * D + h * HD;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            bf16x4 w = {f2bf(o[d][0] * inv), f2bf(o[d][1] * inv), f2bf(o[d][2] * inv), f2bf(o[d][3] * inv)};
+            *reinterpret_cast<bf16x4*>(dst + d * 16 + 4 * g) = w;
+        }
+        if (g == 0 && p.lse2) p.lse2[((size_t)b * p.H + h) * T + q] = m + __builtin_amdgcn_logf(l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// delta[b,h,t] = sum_d dO[t, h*64+d] * O[t, h*64+d]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_delta_kernel(const __bf16* __restrict__ o, const __bf16* __restrict__ dout,
+                                                         float* __restrict__ delta, int B, int T, int H, int D) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long long)B * T) return;
+    const int b = (int)(row / T), tt = (int)(row - (long long)b * T);
+    for (int c0 = 0; c0 < D; c0 += 256) {
+        const int cidx = c0 + lane * 4;
+        float s = 0.f;
+        if (cidx < D) {
+            bf16x4 a = *reinterpret_cast<const bf16x4*>(o + row * D + cidx);
+            bf16x4 d = *reinterpret_cast<const bf16x4*>(dout + row * D + cidx);
+            s = (bf2f(a[0]) * bf2f(d[0]) + bf2f(a[1]) * bf2f(d[1])) + (bf2f(a[2]) * bf2f(d[2]) + bf2f(a[3]) * bf2f(d[3]));
+        }
+        s += dpp_f32<0xB1>(s); s += dpp_f32<0x4E>(s); s += dpp_f32<0x141>(s); s += dpp_f32<0x140>(s);
+        if ((lane & 15) == 0 && cidx < D) delta[((size_t)b * H + cidx / HD) * T + tt] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dQ: same decomposition as forward (query on the lane), K/V tiles stream.
+//   dP^T[key][q] = V . dO^T ;  dS^T = p * (dP^T - delta[q]) * scale ;  dQ^T[d][q] += K^T . dS^T
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * TILE_BYTES];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
+    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int T = p.T, D = p.D;
+    const size_t ld = (size_t)3 * D;
+    const __bf16* seq = p.qkv + (size_t)b * T * ld;
+    const __bf16* kbase = seq + D + h * HD;
+    const __bf16* vbase = seq + 2 * D + h * HD;
+    const float c = p.scale * 1.4426950408889634f;
+
+    const int q = qb * 64 + wave * 16 + i;
+    const int qc = q < T ? q : T - 1;
+    bf16x8 qf[2], dof[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        qf[ks] = *reinterpret_cast<const bf16x8*>(seq + (size_t)qc * ld + h * HD + ks * 32 + g * 8);
+        dof[ks] = *reinterpret_cast<const bf16x8*>(p.dout + ((size_t)b * T + qc) * D + h * HD + ks * 32 + g * 8);
+    }
+    const size_t stat = ((size_t)b * p.H + h) * T + qc;
+    const float lse = p.lse2[stat], dl = p.delta[stat];
+
+    f32x4 dq[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = (T + 63) / 64;
+    stage_rows(kbase, ld, 0, T, lds, wave, lane);
+    stage_rows(vbase, ld, 0, T, lds + TILE_BYTES, wave, lane);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        const char* kt_lds = lds + (kt & 1) * 2 * TILE_BYTES;
+        const char* vt_lds = kt_lds + TILE_BYTES;
+        if (kt + 1 < nkt) {
+            char* nxt = lds + ((kt + 1) & 1) * 2 * TILE_BYTES;
+            stage_rows(kbase, ld, (kt + 1) * 64, T, nxt, wave, lane);
+            stage_rows(vbase, ld, (kt + 1) * 64, T, nxt + TILE_BYTES, wave, lane);
+        }
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int k16 = 0; k16 < 4; ++k16) {
+            s[k16] = dp[k16] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                s[k16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(kt_lds, k16, ks, lane), qf[ks], s[k16], 0, 0, 0);
+                dp[k16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(vt_lds, k16, ks, lane), dof[ks], dp[k16], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int k16 = 0; k16 < 4; ++k16)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 64 + k16 * 16 + 4 * g + r;
+                const float pr = key < T ? __builtin_amdgcn_exp2f(s[k16][r] * c - lse) : 0.f;
+                s[k16][r] = pr * (dp[k16][r] - dl) * p.scale;
+            }
+        bf16x8 db[2] = {pack_pair(s[0], s[1]), pack_pair(s[2], s[3])};
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss)
+                dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(kt_lds, ss, d, lane), db[ss], dq[d], 0, 0, 0);
+    }
+    if (q < T) {
+        __bf16* dst = p.out + ((size_t)b * T + q) * ld + h * HD;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            bf16x4 w = {f2bf(dq[d][0]), f2bf(dq[d][1]), f2bf(dq[d][2]), f2bf(dq[d][3])};
+            *reinterpret_cast<bf16x4*>(dst + d * 16 + 4 * g) = w;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dK, dV: key on the lane, Q / dO tiles stream (each tile serves row reads AND transposed reads).
+//   S[q][key] = Q . K^T ; dP[q][key] = dO . V^T ; P = exp2(c S - lse2[q]) ; dS = P (dP - delta[q]) scale
+//   dV^T[d][key] += dO^T . P ;  dK^T[d][key] += Q^T . dS
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * (2 * TILE_BYTES + 512)];   // [buf][Q|dO|lse,delta]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
+    const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int T = p.T, D = p.D;
+    const size_t ld = (size_t)3 * D;
+    const __bf16* seq = p.qkv + (size_t)b * T * ld;
+    const __bf16* qbase = seq + h * HD;
+    const __bf16* dobase = p.dout + (size_t)b * T * D + h * HD;
+    const float* lse_b = p.lse2 + ((size_t)b * p.H + h) * T;
+    const float* del_b = p.delta + ((size_t)b * p.H + h) * T;
+    const float c = p.scale * 1.4426950408889634f;
+    const int BUF = 2 * TILE_BYTES + 512;
+
+    const int key = kb * 64 + wave * 16 + i;
+    const int kc = key < T ? key : T - 1;
+    bf16x8 kf[2], vf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        kf[ks] = *reinterpret_cast<const bf16x8*>(seq + (size_t)kc * ld + D + h * HD + ks * 32 + g * 8);
+        vf[ks] = *reinterpret_cast<const bf16x8*>(seq + (size_t)kc * ld + 2 * D + h * HD + ks * 32 + g * 8);
+    }
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) dk[d] = dv[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nqt = (T + 63) / 64;
+    // stats for tile qt live in floats [0,64) = lse2, [64,128) = delta of the buffer
+    float stat_next = 0.f;
+    {
+        if (t < 128) { int qq = (t & 63); qq = qq < T ? qq : T - 1; stat_next = (t < 64 ? lse_b : del_b)[qq]; }
+        stage_rows(qbase, ld, 0, T, lds, wave, lane);
+        stage_rows(dobase, (size_t)D, 0, T, lds + TILE_BYTES, wave, lane);
+        if (t < 128) reinterpret_cast<float*>(lds + 2 * TILE_BYTES)[t] = stat_next;
+    }
+    for (int qt = 0; qt < nqt; ++qt) {
+        __syncthreads();
+        const char* cur = lds + (qt & 1) * BUF;
+        const char* q_lds = cur;
+        const char* do_lds = cur + TILE_BYTES;
+        const float* st = reinterpret_cast<const float*>(cur + 2 * TILE_BYTES);
+        char* nxt = lds + ((qt + 1) & 1) * BUF;
+        const bool more = qt + 1 < nqt;
+        if (more) {
+            if (t < 128) {
+                int qq = (qt + 1) * 64 + (t & 63);
+                qq = qq < T ? qq : T - 1;
+                stat_next = (t < 64 ? lse_b : del_b)[qq];
+            }
+            stage_rows(qbase, ld, (qt + 1) * 64, T, nxt, wave, lane);
+            stage_rows(dobase, (size_t)D, (qt + 1) * 64, T, nxt + TILE_BYTES, wave, lane);
+        }
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int q16 = 0; q16 < 4; ++q16) {
+            s[q16] = dp[q16] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                s[q16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(q_lds, q16, ks, lane), kf[ks], s[q16], 0, 0, 0);
+                dp[q16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(do_lds, q16, ks, lane), vf[ks], dp[q16], 0, 0, 0);
+            }
+        }
+        f32x4 pr[4];
+#pragma unroll
+        for (int q16 = 0; q16 < 4; ++q16) {
+            const f32x4 lse4 = *reinterpret_cast<const f32x4*>(st + q16 * 16 + 4 * g);
+            const f32x4 del4 = *reinterpret_cast<const f32x4*>(st + 64 + q16 * 16 + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = qt * 64 + q16 * 16 + 4 * g + r;
+                const float pv = qq < T ? __builtin_amdgcn_exp2f(s[q16][r] * c - lse4[r]) : 0.f;
+                pr[q16][r] = pv;
+                s[q16][r] = pv * (dp[q16][r] - del4[r]) * p.scale;
+            }
+        }
+        bf16x8 pb[2] = {pack_pair(pr[0], pr[1]), pack_pair(pr[2], pr[3])};
+        bf16x8 db[2] = {pack_pair(s[0], s[1]), pack_pair(s[2], s[3])};
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(do_lds, ss, d, lane), pb[ss], dv[d], 0, 0, 0);
+                dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(q_lds, ss, d, lane), db[ss], dk[d], 0, 0, 0);
+            }
+        if (more && t < 128) reinterpret_cast<float*>(nxt + 2 * TILE_BYTES)[t] = stat_next;
+    }
+    if (key < T) {
+        __bf16* dst = p.out + ((size_t)b * T + key) * ld + h * HD;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            bf16x4 wk = {f2bf(dk[d][0]), f2bf(dk[d][1]), f2bf(dk[d][2]), f2bf(dk[d][3])};
+            bf16x4 wv = {f2bf(dv[d][0]), f2bf(dv[d][1]), f2bf(dv[d][2]), f2bf(dv[d][3])};
+            *reinterpret_cast<bf16x4*>(dst + D + d * 16 + 4 * g) = wk;
+            *reinterpret_cast<bf16x4*>(dst + 2 * D + d * 16 + 4 * g) = wv;
+        }
+    }
+}
+
+static int check_attn(const char* fn, int B, int T, int H, int D) {
+    P4P_CHECK(B >= 1 && T >= 1 && H >= 1, "%s: bad sizes B=%d T=%d H=%d", fn, B, T, H);
+    P4P_CHECK(D == H * HD, "%s: only head_dim 64 is built (D=%d, H=%d)", fn, D, H);
+    P4P_CHECK(B <= 65535 && H <= 65535, "%s: grid limit", fn);
+    return 0;
+}
+
+extern "C" int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B, int T, int H, int D, float scale,
+                                 void* stream) {
+    P4P_CHECK(qkv && out, "p4p_attention_fwd: null pointer");
+    if (check_attn("p4p_attention_fwd", B, T, H, D)) return 1;
+    AttnParams p = {};
+    p.qkv = (const __bf16*)qkv; p.out = (__bf16*)out; p.lse2 = lse2; p.B = B; p.T = T; p.H = H; p.D = D; p.scale = scale;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(ceil_div(T, 64), H, B), dim3(ATT_THREADS), 0, (hipStream_t)stream, p);
+    P4P_LAUNCH_CHECK();
+    return 0;
+}
+
+// dqkv receives dq | dk | dv in the layout of qkv.  delta is [B,H,T] workspace.
+extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse2, float* delta,
+                                 void* dqkv, int B, int T, int H, int D, float scale, void* stream) {
+    P4P_CHECK(qkv && o && dout && lse2 && delta && dqkv, "p4p_attention_bwd: null pointer");
+    if (check_attn("p4p_attention_bwd", B, T, H, D)) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(ceil_div((long long)B * T, 4)), dim3(256), 0, st, (const __bf16*)o,
+                       (const __bf16*)dout, delta, B, T, H, D);
+    P4P_LAUNCH_CHECK();
+    AttnParams p = {};
+    p.qkv = (const __bf16*)qkv; p.o = (const __bf16*)o; p.dout = (const __bf16*)dout; p.out = (__bf16*)dqkv;
+    p.lse2 = (float*)lse2; p.delta = delta; p.B = B; p.T = T; p.H = H; p.D = D; p.scale = scale;
+    dim3 grid(ceil_div(T, 64), H, B);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(ATT_THREADS), 0, st, p);
+    P4P_LAUNCH_CHECK();
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(ATT_THREADS), 0, st, p);
+    P4P_LAUNCH_CHECK();
+    return 0;
+}

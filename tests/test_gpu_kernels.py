@@ -1,0 +1,269 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (ctypes).
+
+Integer / index work is compared bit-exactly with the oracle and the reference-generated fixtures;
+floating-point kernels against a plain PyTorch fp32 computation of the same op on the same
+(bf16-rounded) inputs, with the tolerance stated in each test.  No test reads /root/reference.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import p4p_amd                                   # noqa: E402
+from p4p_amd import ops                          # noqa: E402
+from oracle import pix4point_oracle as O         # noqa: E402  (checker only)
+
+DEV = 'cuda'
+
+
+def _loaded():
+    assert os.path.exists(p4p_amd._lib.LIB_PATH)
+    p4p_amd._lib.lib()
+
+
+# ------------------------------------------------------------------------------------------ FPS
+@pytest.mark.parametrize('tag', ['n64', 'n100', 'n1024', 'n2048', 'n8192', 'dup1024'])
+def test_fps_matches_reference_fixture(golden_dir, tag):
+    _loaded()
+    z = np.load(os.path.join(golden_dir, 'fps.npz'))
+    pts = torch.from_numpy(z[f'{tag}_points']).to(DEV)
+    start = torch.from_numpy(z[f'{tag}_start']).to(DEV)
+    got = ops.fps(pts, pts.shape[1] // 4, start)
+    assert got.dtype == torch.int64
+    assert np.array_equal(got.cpu().numpy(), z[f'{tag}_idx'].astype(np.int64))
+
+
+@pytest.mark.parametrize('B,N', [(5, 300), (3, 1000), (2, 4096), (1, 12288)])
+def test_fps_matches_oracle_ragged_sizes(B, N):
+    pts = O.synthetic_clouds(B, N, seed=B * 7 + N)
+    start = torch.randint(0, N, (B,), generator=torch.Generator().manual_seed(N))
+    want = O.farthest_point_sampling(pts, N // 4, start)
+    got = ops.fps(pts.to(DEV), N // 4, start.to(DEV)).cpu()
+    assert torch.equal(got, want)
+
+
+def test_fps_full_size_properties():
+    """BASELINE config sizes (B=256, N=1024 / N=2048): size-independent properties + a sampled oracle check."""
+    for N in (1024, 2048):
+        B = 256
+        pts = O.synthetic_clouds(B, N, seed=99 + N).to(DEV)
+        start = torch.randint(0, N, (B,), device=DEV)
+        idx = ops.fps(pts, N // 4, start)
+        assert idx.shape == (B, N // 4)
+        assert torch.equal(idx[:, 0], start)
+        assert int(idx.min()) >= 0 and int(idx.max()) < N
+        s = torch.sort(idx, dim=1).values
+        assert bool((s[:, 1:] != s[:, :-1]).all()), 'a point was sampled twice'
+        # running min distance to the chosen set must be non-increasing along the sampling order
+        c = torch.gather(pts, 1, idx.unsqueeze(-1).expand(-1, -1, 3))
+        d = torch.cdist(c[:8].double(), c[:8].double())
+        tri = torch.tril(torch.ones(N // 4, N // 4, device=DEV, dtype=torch.bool), -1)
+        dmin = torch.where(tri, d, torch.full_like(d, 1e9)).min(dim=2).values[:, 1:]
+        assert bool((dmin[:, 1:] <= dmin[:, :-1] + 1e-6).all())
+        sel = [0, 17, 255]
+        want = O.farthest_point_sampling(pts[sel].cpu(), N // 4, start[sel].cpu())
+        assert torch.equal(idx[sel].cpu(), want)
+        again = ops.fps(pts, N // 4, start)
+        assert torch.equal(idx, again), 'not deterministic'
+
+
+def test_fps_more_samples_than_points_is_clamped():
+    pts = O.synthetic_clouds(2, 16, seed=1).to(DEV)
+    got = ops.fps(pts, 64, torch.tensor([3, 5], device=DEV))
+    assert got.shape == (2, 16)
+    assert all(sorted(r.tolist()) == list(range(16)) for r in got.cpu())
+
+
+def test_fps_argument_errors():
+    pts = O.synthetic_clouds(2, 64, seed=1)
+    with pytest.raises(RuntimeError):
+        ops.fps(pts, 16)                                   # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        ops.fps(pts.to(DEV).double(), 16)
+    with pytest.raises(RuntimeError):
+        ops.fps(torch.zeros(2, 64, 4, device=DEV), 16)
+
+
+# ------------------------------------------------------------------------------------------ kNN
+@pytest.mark.parametrize('tag', ['n256k16', 'n1024k16', 'n1024k32', 'n2048k16'])
+def test_knn_matches_oracle_and_reference_fixture(golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, 'knn.npz'))
+    pts = torch.from_numpy(z[f'{tag}_points'])
+    cidx = torch.from_numpy(z[f'{tag}_cidx'].astype(np.int64))
+    ref = z[f'{tag}_ref_idx'].astype(np.int32)
+    k = ref.shape[-1]
+    cen = torch.gather(pts, 1, cidx.unsqueeze(-1).expand(-1, -1, 3))
+    got = ops.knn(pts.to(DEV), cen.to(DEV), k).cpu()
+    assert got.dtype == torch.int32
+    assert torch.equal(got, O.knn_indices(cen, pts, k)), 'differs from the exact-distance oracle'
+    clear = z[f'{tag}_min_gap'] > 2e-6
+    assert np.array_equal(got.numpy()[clear], ref[clear]), 'differs from reference cdist+topk on well-separated rows'
+
+
+@pytest.mark.parametrize('B,N,S,k', [(3, 100, 25, 16), (2, 1500, 375, 16), (1, 8192, 2048, 16), (2, 64, 16, 64),
+                                     (1, 3000, 10, 1)])
+def test_knn_matches_oracle_ragged(B, N, S, k):
+    pts = O.synthetic_clouds(B, N, seed=N + k, dup_frac=0.05)
+    cen = pts[:, torch.randperm(N, generator=torch.Generator().manual_seed(1))[:S]].contiguous()
+    want = O.knn_indices(cen, pts, k)
+    got = ops.knn(pts.to(DEV), cen.to(DEV), k).cpu()
+    assert torch.equal(got, want)
+
+
+def test_knn_ties_lowest_index_and_errors():
+    pts = torch.zeros(1, 8, 3)
+    pts[0, :, 0] = torch.tensor([0., 1., -1., 1., 2., -2., 0., 3.])
+    got = ops.knn(pts.to(DEV), pts[:, :1].contiguous().to(DEV), 6).cpu()[0, 0].tolist()
+    assert got == [0, 6, 1, 2, 3, 4]
+    with pytest.raises(RuntimeError):
+        ops.knn(pts.to(DEV), pts[:, :1].contiguous().to(DEV), 9)        # k > N
+
+
+def test_knn_full_size_properties():
+    B, N, k = 256, 1024, 16
+    pts = O.synthetic_clouds(B, N, seed=5).to(DEV)
+    idx = ops.fps(pts, N // 4, torch.zeros(B, dtype=torch.long, device=DEV))
+    cen = torch.gather(pts, 1, idx.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    nb = ops.knn(pts, cen, k)
+    assert nb.shape == (B, N // 4, k)
+    assert torch.equal(nb[..., 0].long(), idx), 'nearest neighbour of a centroid is itself'
+    g = ops.group_gather(pts, nb)
+    d = ((g - cen.unsqueeze(2)) ** 2).sum(-1)
+    assert bool((d[..., 1:] >= d[..., :-1]).all()), 'neighbours not sorted by distance'
+    # the k-th distance is a lower bound for every unselected point (checked on a few clouds)
+    full = torch.cdist(cen[:4], pts[:4]) ** 2
+    kth = d[:4, :, -1:]
+    assert int((full < kth - 1e-6).sum()) <= 4 * (N // 4) * (k - 1)
+    sel = [3, 200]
+    assert torch.equal(nb[sel].cpu(), O.knn_indices(cen[sel].cpu(), pts[sel].cpu(), k))
+    bi = torch.arange(B, device=DEV).view(B, 1, 1)
+    assert torch.equal(g, pts[bi, nb.long()])
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def _int_bf16(shape, lo, hi, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi + 1, shape, generator=g).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (256, 384, 192), (100, 64, 128), (2056, 576, 192), (515, 192, 768),
+                                   (1000, 768, 3072)])
+def test_gemm_tn_exact_on_integer_data(M, N, K):
+    """Small-integer operands make every product and partial sum exact in fp32 and in the bf16
+    output, so any layout / swizzle / k-order mistake shows up as an exact mismatch."""
+    a = _int_bf16((M, K), -2, 2, 1).to(DEV)
+    w = _int_bf16((N, K), -1, 1, 2).to(DEV)
+    if K > 512:
+        w = w * (torch.rand(N, K, device=DEV) < 0.1)      # keep |sum| < 256 so bf16 output is exact
+        w = w.to(torch.bfloat16).contiguous()
+    want = a.float() @ w.float().t()
+    assert float(want.abs().max()) <= 256
+    got = ops.gemm_tn(a, w, ops.EPI_BF16)
+    assert torch.equal(got.float(), want)
+    bias = torch.arange(N, device=DEV, dtype=torch.float32) % 5 - 2
+    got32 = ops.gemm_tn(a, w, ops.EPI_F32_RESID, bias=bias, resid=want.clone())
+    assert torch.equal(got32, 2 * want + bias)
+
+
+def test_gemm_tn_epilogues_random():
+    M, N, K = 777, 320, 256
+    g = torch.Generator().manual_seed(0)
+    a = (torch.randn(M, K, generator=g)).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    ref = a.float() @ w.float().t() + bias
+    out, pre = ops.gemm_tn(a, w, ops.EPI_BF16_GELU, bias=bias, want_pre=True)
+    # tolerance: one bf16 rounding of the output (2^-8 relative) on top of fp32 accumulation
+    torch.testing.assert_close(pre.float(), ref, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(out.float(), torch.nn.functional.gelu(ref), rtol=1e-2, atol=1e-2)
+    dg = ops.gemm_tn(a, w, ops.EPI_BF16_DGELU, pre=pre)
+    x = pre.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    torch.testing.assert_close(dg.float(), (a.float() @ w.float().t()) * x.grad, rtol=2e-2, atol=2e-2)
+    # row-group broadcast + column statistics
+    grp = 7
+    rg = torch.randn(M // grp, N, generator=g).to(DEV)
+    out, st = ops.gemm_tn(a, w, ops.EPI_BF16_ROWGROUP, rowgrp=rg, group=grp)
+    full = a.float() @ w.float().t() + rg.repeat_interleave(grp, 0)
+    torch.testing.assert_close(out.float(), full, rtol=1e-2, atol=1e-2)
+    s = st.sum(0)
+    torch.testing.assert_close(s[0], full.sum(0), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(s[1], (full * full).sum(0), rtol=1e-4, atol=1e-2)
+    out, st = ops.gemm_tn(a, w, ops.EPI_BF16_STATS, bias=bias)
+    torch.testing.assert_close(st.sum(0)[0], ref.sum(0), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize('M,N,K', [(64, 128, 128), (200, 256, 192), (2056, 576, 192), (4099, 192, 768), (1000, 8, 64)])
+def test_gemm_wgrad_exact_on_integer_data(M, N, K):
+    g = _int_bf16((M, N), -1, 1, 3).to(DEV)
+    a = _int_bf16((M, K), -2, 2, 4).to(DEV)
+    want = g.float().t() @ a.float()
+    got = ops.gemm_wgrad(g, a)
+    assert torch.equal(got, want)
+    acc = ops.gemm_wgrad(g, a, out=got.clone(), beta=1.0)
+    assert torch.equal(acc, 2 * want)
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize('M,D', [(33, 192), (257, 384), (1000, 768), (64, 1024)])
+def test_layernorm_fwd_bwd(M, D):
+    g = torch.Generator().manual_seed(D)
+    x = torch.randn(M, D, generator=g).to(DEV)
+    pos = torch.randn(M, D, generator=g).to(DEV)
+    gamma = (torch.randn(D, generator=g) * 0.1 + 1).to(DEV)
+    beta = (torch.randn(D, generator=g) * 0.1).to(DEV)
+    y, xs, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-6, pos=pos, want_sum=True, out_f32=True)
+    xr = (x + pos).requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gamma, beta, 1e-6)
+    assert torch.equal(xs, x + pos)
+    torch.testing.assert_close(y, ref, rtol=1e-5, atol=1e-5)          # fp32 in, fp32 out
+    yb, _, _, _ = ops.layernorm_fwd(x, gamma, beta, 1e-6, pos=pos)
+    torch.testing.assert_close(yb.float(), ref, rtol=8e-3, atol=8e-3)  # one bf16 rounding
+    dy = torch.randn(M, D, generator=g).to(DEV)
+    gr = torch.nn.Parameter(gamma.clone())
+    br = torch.nn.Parameter(beta.clone())
+    torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6).backward(dy)
+    base = torch.randn(M, D, generator=g).to(DEV)
+    dx, dg, db = ops.layernorm_bwd(dy, xs, mean, rstd, gamma, dx=base.clone())
+    torch.testing.assert_close(dx, base + xr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dg, gr.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(db, br.grad, rtol=1e-4, atol=1e-3)
+    dx2, _, _ = ops.layernorm_bwd(dy.to(torch.bfloat16), xs, mean, rstd, gamma)
+    torch.testing.assert_close(dx2, xr.grad, rtol=2e-2, atol=2e-2)
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _attn_ref(qkv, B, T, H):
+    D = qkv.shape[1] // 3
+    x = qkv.float().reshape(B, T, 3, H, D // H).permute(2, 0, 3, 1, 4)
+    q, k, v = x[0], x[1], x[2]
+    a = ((q @ k.transpose(-2, -1)) * (D // H) ** -0.5).softmax(-1)
+    return (a @ v).transpose(1, 2).reshape(B * T, D)
+
+
+@pytest.mark.parametrize('B,T,H', [(2, 1, 1), (2, 17, 3), (3, 64, 2), (2, 65, 3), (2, 257, 3), (1, 513, 2), (1, 2049, 1)])
+def test_attention_fwd_bwd(B, T, H):
+    D = 64 * H
+    g = torch.Generator().manual_seed(T)
+    qkv = (torch.randn(B * T, 3 * D, generator=g) * 1.5).to(torch.bfloat16).to(DEV)
+    out, lse = ops.attention_fwd(qkv, B, T, H)
+    qr = qkv.float().requires_grad_(True)
+    ref = _attn_ref(qr, B, T, H)
+    # tolerance: P and the output are rounded to bf16 (2^-8); values are O(1)
+    torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-2)
+    dout = torch.randn(B * T, D, generator=g).to(torch.bfloat16).to(DEV)
+    ref.backward(dout.float())
+    dqkv = ops.attention_bwd(qkv, out, dout, lse, B, T, H)
+    err = (dqkv.float() - qr.grad).abs().max().item()
+    scale = qr.grad.abs().max().item()
+    assert err <= 3e-2 * max(scale, 1.0), (err, scale)
+    # forces the online-softmax rescale: one key dominates late in the sequence
+    if T >= 65:
+        spike = qkv.clone().view(B, T, 3, H, 64)
+        spike[:, T - 1, 1] = spike[:, 0, 0] * 4
+        spike = spike.view(B * T, 3 * D).contiguous()
+        out2, _ = ops.attention_fwd(spike, B, T, H)
+        torch.testing.assert_close(out2.float(), _attn_ref(spike, B, T, H), rtol=2e-2, atol=2e-2)
