@@ -1,0 +1,163 @@
+// Streaming helpers around the GEMMs (all HBM-bound, 8-16 B per lane):
+//   * fp32 master weight -> bf16 operand copies W and W^T (once per optimizer step);
+//   * bias gradients: column sums of a bf16 [M,N] gradient (autograd of nn.Linear.bias);
+//   * row remaps between the token stream [B*T,D] (cls row first, src/models/pix4point.py:248-252)
+//     and the compact patch rows [B*S,D].
+#include "common.h"
+
+// dst[r][c] = bf16(src[r*ld + c]);  dstT[c][r] = same.  32x32 tiles through LDS.
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, long long ld,
+                                                             __bf16* __restrict__ dst, __bf16* __restrict__ dstT,
+                                                             int R, int C) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ty + j * 8, c = c0 + tx;
+        float v = (r < R && c < C) ? src[(size_t)r * ld + c] : 0.f;
+        tile[ty + j * 8][tx] = v;
+        if (dst && r < R && c < C) dst[(size_t)r * C + c] = f2bf(v);
+    }
+    if (!dstT) return;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + ty + j * 8, r = r0 + tx;
+        if (r < R && c < C) dstT[(size_t)c * R + r] = f2bf(tile[tx][ty + j * 8]);
+    }
+}
+
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long long n) {
+    long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (e + 3 < n) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(src + e);
+        bf16x4 w = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *reinterpret_cast<bf16x4*>(dst + e) = w;
+    } else {
+        for (; e < n; ++e) dst[e] = f2bf(src[e]);
+    }
+}
+
+// partial[split][n] = sum over the split's rows of G[m][n]; 256 threads = 64 column quads x 4 row lanes
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restrict__ G, float* __restrict__ partial,
+                                                          int M, int N, int rows_per_split) {
+    __shared__ f32x4 red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = blockIdx.x * 256 + tx * 4;
+    const int m_begin = blockIdx.y * rows_per_split;
+    const int m_end = min(M, m_begin + rows_per_split);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+        for (int m = m_begin + ty; m < m_end; m += 4) {
+            bf16x4 w = *reinterpret_cast<const bf16x4*>(G + (size_t)m * N + n);
+            acc += f32x4{bf2f(w[0]), bf2f(w[1]), bf2f(w[2]), bf2f(w[3])};
+        }
+    }
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && n < N) {
+        f32x4 s = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        *reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.y * N + n) = s;
+    }
+}
+
+__global__ void colreduce2_kernel(const float* __restrict__ part, float* __restrict__ out, int nrows, int ncols,
+                                  float beta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    float s = 0.f;
+    for (int r = 0; r < nrows; ++r) s += part[(size_t)r * ncols + c];
+    out[c] = beta != 0.f ? beta * out[c] + s : s;
+}
+
+// Token stream <-> compact patch rows.  stream row of patch (b,s) = b*T + 1 + s  (T = S + 1).
+// mode 0: compact_bf16[m] = bf16(stream_f32[row(m)])      (gradient of the patch tokens)
+// mode 1: stream_f32[row(m)] = compact_f32[m]             (assemble tokens / positional embedding)
+__global__ void token_rows_kernel(float* __restrict__ stream, void* __restrict__ compact, long long n_compact, int S,
+                                  int D, int mode) {
+    long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (e >= n_compact) return;
+    long long m = e / D;
+    int c = (int)(e - m * D);
+    long long row = m + m / S + 1;
+    if (mode == 0) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(stream + row * D + c);
+        bf16x4 w = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *reinterpret_cast<bf16x4*>((__bf16*)compact + e) = w;
+    } else {
+        *reinterpret_cast<f32x4*>(stream + row * D + c) = *reinterpret_cast<const f32x4*>((const float*)compact + e);
+    }
+}
+
+// cls rows: mode 1: stream[b*T] = vec;  mode 0: out[c] = sum_b stream[b*T][c]
+__global__ void cls_rows_kernel(float* __restrict__ stream, float* __restrict__ vec, int B, int T, int D, int mode) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= D) return;
+    if (mode == 1) {
+        const float v = vec[c];
+        for (int b = blockIdx.y; b < B; b += gridDim.y) stream[(size_t)b * T * D + c] = v;
+    } else {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += stream[(size_t)b * T * D + c];
+        vec[c] = s;
+    }
+}
+
+extern "C" int p4p_cast_transpose_f32_bf16(const float* src, long long ld_src, void* dst, void* dstT, int R, int C,
+                                           void* stream) {
+    P4P_CHECK(src && (dst || dstT) && R >= 1 && C >= 1 && ld_src >= C, "p4p_cast_transpose_f32_bf16: bad arguments");
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3(ceil_div(C, 32), ceil_div(R, 32)), dim3(256), 0,
+                       (hipStream_t)stream, src, ld_src, (__bf16*)dst, (__bf16*)dstT, R, C);
+    P4P_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int p4p_cast_f32_bf16(const float* src, void* dst, long long n, void* stream) {
+    P4P_CHECK(src && dst && n >= 0, "p4p_cast_f32_bf16: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ceil_div((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       (__bf16*)dst, n);
+    P4P_LAUNCH_CHECK();
+    return 0;
+}
+
+#define COLSUM_MAX_SPLITS 256
+extern "C" int p4p_colsum_splits(int M) {
+    int s = ceil_div(M, 256);
+    return s < 1 ? 1 : (s > COLSUM_MAX_SPLITS ? COLSUM_MAX_SPLITS : s);
+}
+
+// out[N] f32 = beta*out + column sums of G[M,N] bf16.  workspace: p4p_colsum_splits(M)*N floats.
+extern "C" int p4p_colsum_bf16(const void* G, float* out, float* workspace, int M, int N, float beta, void* stream) {
+    P4P_CHECK(G && out && workspace, "p4p_colsum_bf16: null pointer");
+    P4P_CHECK(M >= 1 && N >= 4 && N % 4 == 0, "p4p_colsum_bf16: bad sizes M=%d N=%d", M, N);
+    hipStream_t st = (hipStream_t)stream;
+    int splits = p4p_colsum_splits(M);
+    int rps = ceil_div(M, splits);
+    splits = ceil_div(M, rps);
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(ceil_div(N, 256), splits), dim3(256), 0, st, (const __bf16*)G, workspace,
+                       M, N, rps);
+    P4P_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colreduce2_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, workspace, out, splits, N, beta);
+    P4P_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int p4p_token_rows(float* stream_f32, void* compact, int B, int S, int D, int mode, void* stream) {
+    P4P_CHECK(stream_f32 && compact && B >= 1 && S >= 1 && D >= 4 && D % 4 == 0 && (mode == 0 || mode == 1),
+              "p4p_token_rows: bad arguments");
+    long long n = (long long)B * S * D;
+    hipLaunchKernelGGL(token_rows_kernel, dim3(ceil_div(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, stream_f32,
+                       compact, n, S, D, mode);
+    P4P_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int p4p_cls_rows(float* stream_f32, float* vec, int B, int T, int D, int mode, void* stream) {
+    P4P_CHECK(stream_f32 && vec && B >= 1 && T >= 1 && D >= 1 && (mode == 0 || mode == 1), "p4p_cls_rows: bad arguments");
+    dim3 grid(ceil_div(D, 256), mode == 1 ? (B < 64 ? B : 64) : 1);
+    hipLaunchKernelGGL(cls_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, stream_f32, vec, B, T, D, mode);
+    P4P_LAUNCH_CHECK();
+    return 0;
+}

@@ -78,6 +78,8 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(const void* _
                                                                     const float* __restrict__ rstd,
                                                                     const float* __restrict__ gamma,
                                                                     float* __restrict__ dx, int accumulate,
+                                                                    __bf16* __restrict__ dx_bf16,
+                                                                    float* __restrict__ dacc, int dacc_init,
                                                                     float* __restrict__ partial, int M, int D) {
     __shared__ float red[LN_THREADS / 64][2][256 * J];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -122,6 +124,14 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(const void* _
                 f32x4 o = (d[j] * g[j] - m1 - xh[j] * m2) * rs;
                 if (accumulate) o += *reinterpret_cast<const f32x4*>(dx + base + c);
                 *reinterpret_cast<f32x4*>(dx + base + c) = o;
+                if (dx_bf16) {
+                    bf16x4 w = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+                    *reinterpret_cast<bf16x4*>(dx_bf16 + base + c) = w;
+                }
+                if (dacc) {
+                    f32x4 a = dacc_init ? o : o + *reinterpret_cast<const f32x4*>(dacc + base + c);
+                    *reinterpret_cast<f32x4*>(dacc + base + c) = a;
+                }
             }
         }
     }
@@ -182,8 +192,8 @@ extern "C" int p4p_layernorm_fwd(const float* x, const float* pos, const float* 
 // partial: [LN_BWD_BLOCKS][2][D] floats of workspace; dgamma/dbeta = beta_acc * old + column sums.
 extern "C" int p4p_layernorm_bwd(const void* dy, int dy_is_f32, const float* xin, const float* mean,
                                  const float* rstd, const float* gamma, float* dx, int accumulate_dx,
-                                 float* partial, float* dgamma, float* dbeta, float beta_acc, int M, int D,
-                                 void* stream) {
+                                 void* dx_bf16, float* dacc, int dacc_init, float* partial, float* dgamma,
+                                 float* dbeta, float beta_acc, int M, int D, void* stream) {
     P4P_CHECK(dy && xin && mean && rstd && gamma && dx && partial, "p4p_layernorm_bwd: null pointer");
     P4P_CHECK(M >= 1 && D >= 4 && D % 4 == 0 && D <= 2048, "p4p_layernorm_bwd: bad sizes M=%d D=%d", M, D);
     hipStream_t st = (hipStream_t)stream;
@@ -192,7 +202,7 @@ extern "C" int p4p_layernorm_bwd(const void* dy, int dy_is_f32, const float* xin
     dim3 grid(blocks), blk(LN_THREADS);
     int J = ceil_div(D, 256);
 #define LN_BWD(JJ) hipLaunchKernelGGL(layernorm_bwd_kernel<JJ>, grid, blk, 0, st, dy, dy_is_f32, xin, mean, rstd, gamma, \
-                                      dx, accumulate_dx, partial, M, D)
+                                      dx, accumulate_dx, (__bf16*)dx_bf16, dacc, dacc_init, partial, M, D)
     if (J <= 1) LN_BWD(1); else if (J <= 2) LN_BWD(2); else if (J <= 3) LN_BWD(3); else if (J <= 4) LN_BWD(4); else LN_BWD(8);
 #undef LN_BWD
     P4P_LAUNCH_CHECK();

@@ -1,0 +1,247 @@
+"""Autograd wiring of the HIP kernels.  Three differentiable units cover the hot path:
+
+* ``p3embed``  - FPS + kNN + local MLP tokenizer   (reference src/models/pix4point.py:166-191)
+* ``linear``   - nn.Linear on bf16 MFMA            (PointViT.proj / pos_embed[2], :213-218,245-246)
+* ``encoder``  - L x timm Block + final LayerNorm  (:254-256), positional embedding re-added per block
+
+Forward and backward both run hand-written kernels; torch is only the allocator, the stream and
+the autograd graph.  Saved activations are bf16 except the fp32 residual stream.
+"""
+import torch
+
+from . import ops
+
+def _bf16_weights(w, want_t, col0=0, cols=None):
+    """bf16 operand copies (W, W^T) of an fp32 master weight.  The cache lives ON the parameter object
+    (so it dies with it) and is invalidated by the tensor's version counter (any in-place update)."""
+    cache = getattr(w, '_p4p_bf16', None)
+    if cache is None:
+        cache = {}
+        w._p4p_bf16 = cache
+    ent = cache.get((col0, cols))
+    if (ent is not None and ent[0] == w._version and ent[3] == w.data_ptr()
+            and (ent[2] is not None or not want_t)):
+        return ent[1], ent[2]
+    wb, wt = ops.cast_weight(w.detach(), True, want_t, cols=cols, col0=col0)
+    cache[(col0, cols)] = (w._version, wb, wt, w.data_ptr())
+    return wb, wt
+
+
+# ================================================================================================
+# tokenizer
+# ================================================================================================
+class _P3EmbedFn(torch.autograd.Function):
+    """tokens f32 [B*S, E] = P3Embed local MLP over the kNN groups (one stage)."""
+
+    @staticmethod
+    def forward(ctx, points, feats, idx, k, training, need_bwd, bns, W1, W2, b2, g1, be1, W3, g2, be2, W4, g3, be3):
+        bn1, bn2, bn3 = bns
+        B, N, _ = points.shape
+        S = idx.shape[1]
+        G, P = B * S, B * S * k
+        C1 = W2.shape[0]
+        W1m, W2m = W1.detach().reshape(C1, 6), W2.detach().reshape(C1, C1)
+        mom_part = ops.embed_moments(points, feats, idx) if training else None
+        aeff, sc1, sh1, mean1, is1, mom = ops.embed_fold(W1m, W2m, b2.detach(), bn1, mom_part, P, training)
+        F1, pooled, arg1 = ops.embed_stage1(points, feats, idx, aeff, sc1, sh1)
+        W3a, W3aT = _bf16_weights(W3, need_bwd, 0, C1)
+        W3b, W3bT = _bf16_weights(W3, need_bwd, C1, W3.shape[1] - C1)
+        U = ops.gemm_tn(pooled, W3a, ops.EPI_F32_RESID)
+        H2, st2 = ops.gemm_tn(F1, W3b, ops.EPI_BF16_ROWGROUP, rowgrp=U, group=k)
+        C2 = H2.shape[1]
+        sums2 = ops.colreduce(st2, st2.shape[0], 2 * C2) if training else None
+        sc2, sh2, mean2, is2 = ops.bn_finalize(sums2, bn2, P, training)
+        F2 = ops.bn_relu(H2, sc2, sh2)
+        W4b, W4T = _bf16_weights(W4, need_bwd)
+        H3, st3 = ops.gemm_tn(F2, W4b, ops.EPI_BF16_STATS)
+        C3 = H3.shape[1]
+        sums3 = ops.colreduce(st3, st3.shape[0], 2 * C3) if training else None
+        sc3, sh3, mean3, is3 = ops.bn_finalize(sums3, bn3, P, training)
+        tok, arg3 = ops.bn_relu_maxpool(H3, sc3, sh3, G, k)
+        if training:
+            for bn in bns:
+                bn.num_batches_tracked += 1
+        ctx.training, ctx.k, ctx.dims = training, k, (B, N, S, C1, C2, C3)
+        ctx.save_for_backward(points, feats, idx, W1, W2, g1, F1, pooled, arg1, aeff, mom, is1, H2, F2, sc2, sh2,
+                              mean2, is2, H3, arg3, sc3, sh3, mean3, is3, W3aT, W3bT, W4T)
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        if not ctx.training:
+            raise RuntimeError('P3Embed backward is implemented for train-mode BatchNorm only '
+                               '(the reference never back-propagates in eval mode)')
+        (points, feats, idx, W1, W2, g1, F1, pooled, arg1, aeff, mom, is1, H2, F2, sc2, sh2, mean2, is2, H3, arg3, sc3,
+         sh3, mean3, is3, W3aT, W3bT, W4T) = ctx.saved_tensors
+        B, N, S, C1, C2, C3 = ctx.dims
+        k, G = ctx.k, B * S
+        dtok = dtok.contiguous()
+        dH3, s3 = ops.pool_bn_bwd(dtok, H3, arg3, sc3, sh3, mean3, is3, G, k)
+        dW4 = ops.gemm_wgrad(dH3, F2)
+        dF2 = ops.gemm_tn(dH3, W4T, ops.EPI_BF16)
+        s2 = ops.relu_bn_bwd_(dF2, H2, sc2, sh2, mean2, is2)          # dF2 now holds dH2
+        dW3b = ops.gemm_wgrad(dF2, F1)
+        dF1 = ops.gemm_tn(dF2, W3bT, ops.EPI_BF16)
+        dU = ops.group_sum(dF2, G, k)
+        dW3a = ops.gemm_wgrad(dU, pooled)
+        dPooled = ops.gemm_tn(dU, W3aT, ops.EPI_BF16)
+        dW1, dW2, db2, dg1, db1 = ops.embed_stage1_bwd(points, feats, idx, F1, dF1, dPooled, arg1, mom, aeff,
+                                                       W1.detach().reshape(C1, 6), W2.detach().reshape(C1, C1),
+                                                       g1.detach(), is1)
+        dW3 = torch.cat([dW3a, dW3b], dim=1)
+        return (None, None, None, None, None, None, None, dW1.view_as(W1), dW2.view_as(W2), db2, dg1, db1, dW3.view(C2, C2, 1, 1),
+                s2[1].clone(), s2[0].clone(), dW4.view(C3, C2, 1, 1), s3[1].clone(), s3[0].clone())
+
+
+def p3embed(points, feats_bnc, idx, k, training, convs):
+    """convs = P3Embed.convs[i] (ModuleList[conv1 Sequential, conv2 Sequential], pix4point.py:135-158)."""
+    c1, c2 = convs[0], convs[1]
+    bns = (c1[2], c2[1], c2[4])
+    need_bwd = bool(training and torch.is_grad_enabled() and any(p.requires_grad for p in convs.parameters()))
+    return _P3EmbedFn.apply(points, feats_bnc, idx, k, training, need_bwd, bns, c1[0].weight, c1[1].weight, c1[1].bias,
+                            c1[2].weight, c1[2].bias, c2[0].weight, c2[1].weight, c2[1].bias, c2[3].weight,
+                            c2[4].weight, c2[4].bias)
+
+
+# ================================================================================================
+# Linear
+# ================================================================================================
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x2 = x.reshape(-1, x.shape[-1])
+        xb = ops.cast_bf16(x2.contiguous()) if x2.dtype == torch.float32 else x2.contiguous()
+        need_t = ctx.needs_input_grad[0]
+        Wb, Wt = _bf16_weights(W, need_t)
+        y = ops.gemm_tn(xb, Wb, ops.EPI_F32_RESID, bias=b.detach() if b is not None else None)
+        ctx.save_for_backward(xb, Wt)
+        ctx.has_bias, ctx.xshape = b is not None, x.shape
+        return y.view(*x.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, Wt = ctx.saved_tensors
+        g = ops.cast_bf16(dy.reshape(-1, dy.shape[-1]).contiguous())
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm_tn(g, Wt, ops.EPI_F32_RESID).view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            dW = ops.gemm_wgrad(g, xb)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.colsum(g)
+        return dx, dW, db
+
+
+def linear(x, weight, bias):
+    return _LinearFn.apply(x, weight, bias)
+
+
+# ================================================================================================
+# ViT encoder: L blocks + final norm
+# ================================================================================================
+_BLOCK_PARAMS = 12     # n1w n1b qkvw qkvb projw projb n2w n2b fc1w fc1b fc2w fc2b
+
+
+def block_params(blk):
+    return [blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight,
+            blk.attn.proj.bias, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
+            blk.mlp.fc2.weight, blk.mlp.fc2.bias]
+
+
+class _EncoderFn(torch.autograd.Function):
+    """feats, pos: f32 [B,T,D].  For every block: x = blk(x + pos); then the final LayerNorm."""
+
+    @staticmethod
+    def forward(ctx, feats, pos, num_heads, eps, grad_sink, train, norm_w, norm_b, *bp):
+        B, T, D = feats.shape
+        M, H = B * T, num_heads
+        L = len(bp) // _BLOCK_PARAMS
+        x = feats.reshape(M, D)
+        pos2 = pos.reshape(M, D).contiguous()
+        x = x.contiguous()
+        saved = []
+        for l in range(L):
+            n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = bp[l * _BLOCK_PARAMS:(l + 1) * _BLOCK_PARAMS]
+            ln1, xin, mean1, rstd1 = ops.layernorm_fwd(x, n1w.detach(), n1b.detach(), eps, pos=pos2, want_sum=True,
+                                                       want_stats=train)
+            Wqkv, _ = _bf16_weights(qkvw, train)
+            qkv = ops.gemm_tn(ln1, Wqkv, ops.EPI_BF16, bias=qkvb.detach())
+            att, lse = ops.attention_fwd(qkv, B, T, H, want_lse=train)
+            Wproj, _ = _bf16_weights(projw, train)
+            x1 = ops.gemm_tn(att, Wproj, ops.EPI_F32_RESID, bias=projb.detach(), resid=xin)
+            ln2, _, mean2, rstd2 = ops.layernorm_fwd(x1, n2w.detach(), n2b.detach(), eps, want_stats=train)
+            Wfc1, _ = _bf16_weights(fc1w, train)
+            if train:
+                g, hpre = ops.gemm_tn(ln2, Wfc1, ops.EPI_BF16_GELU, bias=fc1b.detach(), want_pre=True)
+            else:
+                g, hpre = ops.gemm_tn(ln2, Wfc1, ops.EPI_BF16_GELU, bias=fc1b.detach()), None
+            Wfc2, _ = _bf16_weights(fc2w, train)
+            x = ops.gemm_tn(g, Wfc2, ops.EPI_F32_RESID, bias=fc2b.detach(), resid=x1)
+            if train:
+                saved += [xin, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, hpre, g]
+        y, _, meanN, rstdN = ops.layernorm_fwd(x, norm_w.detach(), norm_b.detach(), eps, out_f32=True, want_stats=train)
+        if train:
+            ctx.save_for_backward(x, meanN, rstdN, norm_w, *bp, *saved)
+        ctx.meta = (B, T, D, H, L, eps)
+        ctx.grad_sink = grad_sink
+        return y.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, D, H, L, eps = ctx.meta
+        M = B * T
+        t = ctx.saved_tensors
+        xN, meanN, rstdN, norm_w = t[:4]
+        bp = t[4:4 + L * _BLOCK_PARAMS]
+        saved = t[4 + L * _BLOCK_PARAMS:]
+        need = ctx.needs_input_grad           # feats, pos, heads, eps, sink, train, norm_w, norm_b, *bp
+        dev = dy.device
+        dxb = torch.empty(M, D, dtype=torch.bfloat16, device=dev)
+        dx, dnw, dnb = ops.layernorm_bwd(dy.reshape(M, D).contiguous(), xN, meanN, rstdN, norm_w.detach(), dx_bf16=dxb)
+        dpos = torch.empty(M, D, dtype=torch.float32, device=dev)
+        grads = [None] * (L * _BLOCK_PARAMS)
+        sink = ctx.grad_sink
+        for l in reversed(range(L)):
+            n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = bp[l * _BLOCK_PARAMS:(l + 1) * _BLOCK_PARAMS]
+            xin, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, hpre, g = saved[l * 13:(l + 1) * 13]
+            wg = need[8 + l * _BLOCK_PARAMS + 2]       # block weights trainable? (frozen ViT => False)
+            # ---- mlp: x = x1 + fc2(gelu(fc1(ln2)))
+            _, Wfc2T = _bf16_weights(fc2w, True)
+            dh = ops.gemm_tn(dxb, Wfc2T, ops.EPI_BF16_DGELU, pre=hpre)
+            _, Wfc1T = _bf16_weights(fc1w, True)
+            dln2 = ops.gemm_tn(dh, Wfc1T, ops.EPI_BF16)
+            if wg:
+                dfc2w, dfc2b = ops.gemm_wgrad(dxb, g), ops.colsum(dxb)
+                dfc1w, dfc1b = ops.gemm_wgrad(dh, ln2), ops.colsum(dh)
+            del dh
+            _, dn2w, dn2b = ops.layernorm_bwd(dln2, x1, mean2, rstd2, n2w.detach(), dx=dx, dx_bf16=dxb)
+            # ---- attention: x1 = xin + proj(attn(qkv(ln1)))
+            _, WprojT = _bf16_weights(projw, True)
+            datt = ops.gemm_tn(dxb, WprojT, ops.EPI_BF16)
+            if wg:
+                dprojw, dprojb = ops.gemm_wgrad(dxb, att), ops.colsum(dxb)
+            dqkv = ops.attention_bwd(qkv, att, datt, lse, B, T, H)
+            _, WqkvT = _bf16_weights(qkvw, True)
+            dln1 = ops.gemm_tn(dqkv, WqkvT, ops.EPI_BF16)
+            if wg:
+                dqkvw, dqkvb = ops.gemm_wgrad(dqkv, ln1), ops.colsum(dqkv)
+            del dqkv, datt
+            _, dn1w, dn1b = ops.layernorm_bwd(dln1, xin, mean1, rstd1, n1w.detach(), dx=dx, dx_bf16=dxb, dacc=dpos,
+                                              dacc_init=(l == L - 1))
+            if wg:
+                grads[l * _BLOCK_PARAMS:(l + 1) * _BLOCK_PARAMS] = [dn1w, dn1b, dqkvw, dqkvb, dprojw, dprojb, dn2w, dn2b,
+                                                                    dfc1w, dfc1b, dfc2w, dfc2b]
+                if sink is not None:
+                    grads[l * _BLOCK_PARAMS:(l + 1) * _BLOCK_PARAMS] = sink.block_ready(
+                        l, bp[l * _BLOCK_PARAMS:(l + 1) * _BLOCK_PARAMS], grads[l * _BLOCK_PARAMS:(l + 1) * _BLOCK_PARAMS])
+        if L == 0:
+            dpos.zero_()
+        return (dx.view(B, T, D), dpos.view(B, T, D), None, None, None, None, dnw, dnb, *grads)
+
+
+def encoder(feats, pos, blocks, norm, num_heads, grad_sink=None):
+    bp = []
+    for blk in blocks:
+        bp += block_params(blk)
+    train = bool(torch.is_grad_enabled() and any(t.requires_grad for t in (feats, pos, norm.weight, *bp)))
+    return _EncoderFn.apply(feats, pos, num_heads, norm.eps, grad_sink, train, norm.weight, norm.bias, *bp)

@@ -146,8 +146,10 @@ def layernorm_fwd(x, gamma, beta, eps=1e-6, pos=None, want_sum=False, out_f32=Fa
     return y, xsum, mean, rstd
 
 
-def layernorm_bwd(dy, xin, mean, rstd, gamma, dx=None, dgamma=None, dbeta=None, beta_acc=0.0):
-    """Returns (dx, dgamma, dbeta); if dx is given the LN gradient is ADDED to it in place."""
+def layernorm_bwd(dy, xin, mean, rstd, gamma, dx=None, dgamma=None, dbeta=None, beta_acc=0.0, dx_bf16=None,
+                  dacc=None, dacc_init=False):
+    """Returns (dx, dgamma, dbeta); if dx is given the LN gradient is ADDED to it in place.  dx_bf16 gets a
+    bf16 copy of the result, dacc accumulates it (positional-embedding gradient)."""
     M, D = xin.shape
     _chk(dy, 'dy', None, 2)
     if dy.dtype not in (torch.float32, torch.bfloat16):
@@ -162,8 +164,8 @@ def layernorm_bwd(dy, xin, mean, rstd, gamma, dx=None, dgamma=None, dbeta=None, 
     rows = L.call_int('p4p_layernorm_bwd_partial_rows')
     part = _workspace('lnbwd', rows * 2 * D, xin.device)
     L.call('p4p_layernorm_bwd', L.ptr(dy), int(dy.dtype == torch.float32), L.ptr(xin), L.ptr(mean), L.ptr(rstd),
-           L.ptr(gamma), L.ptr(dx), int(acc), L.ptr(part), L.ptr(dgamma), L.ptr(dbeta), float(beta_acc), M, D,
-           _stream())
+           L.ptr(gamma), L.ptr(dx), int(acc), L.ptr(dx_bf16), L.ptr(dacc), int(dacc_init), L.ptr(part), L.ptr(dgamma),
+           L.ptr(dbeta), float(beta_acc), M, D, _stream())
     return dx, dgamma, dbeta
 
 
@@ -190,3 +192,165 @@ def attention_bwd(qkv, o, dout, lse, B, T, H):
     L.call('p4p_attention_bwd', L.ptr(qkv), L.ptr(o), L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dqkv), B, T, H, D,
            float((D // H) ** -0.5), _stream())
     return dqkv
+
+
+# ---------------------------------------------------------------- streaming helpers
+def cast_weight(w, want=True, want_t=False, rows=None, cols=None, col0=0):
+    """fp32 weight (2-D view, possibly a column slice [:, col0:col0+cols]) -> (bf16 W, bf16 W^T)."""
+    w2 = w.reshape(w.shape[0], -1)
+    R = w2.shape[0] if rows is None else rows
+    C = (w2.shape[1] - col0) if cols is None else cols
+    _chk(w2, 'w', torch.float32, 2)
+    dst = torch.empty(R, C, dtype=torch.bfloat16, device=w.device) if want else None
+    dst_t = torch.empty(C, R, dtype=torch.bfloat16, device=w.device) if want_t else None
+    src_ptr = L.ctypes.c_void_p(w2.data_ptr() + 4 * col0)
+    L.call('p4p_cast_transpose_f32_bf16', src_ptr, L.i64(w2.shape[1]), L.ptr(dst), L.ptr(dst_t), R, C, _stream())
+    return dst, dst_t
+
+
+def cast_bf16(x):
+    _chk(x, 'x', torch.float32)
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    L.call('p4p_cast_f32_bf16', L.ptr(x), L.ptr(out), L.i64(x.numel()), _stream())
+    return out
+
+
+def colsum(g, out=None, beta=0.0):
+    _chk(g, 'g', torch.bfloat16, 2)
+    M, N = g.shape
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=g.device)
+        beta = 0.0
+    ws = _workspace('colsum', L.call_int('p4p_colsum_splits', M) * N, g.device)
+    L.call('p4p_colsum_bf16', L.ptr(g), L.ptr(out), L.ptr(ws), M, N, float(beta), _stream())
+    return out
+
+
+def token_rows_to_compact(stream, B, S, D):
+    out = torch.empty(B * S, D, dtype=torch.bfloat16, device=stream.device)
+    L.call('p4p_token_rows', L.ptr(stream), L.ptr(out), B, S, D, 0, _stream())
+    return out
+
+
+def compact_to_token_rows(stream, compact, B, S, D):
+    _chk(compact, 'compact', torch.float32)
+    L.call('p4p_token_rows', L.ptr(stream), L.ptr(compact), B, S, D, 1, _stream())
+
+
+def cls_rows_set(stream, vec, B, T, D):
+    L.call('p4p_cls_rows', L.ptr(stream), L.ptr(vec), B, T, D, 1, _stream())
+
+
+def cls_rows_sum(stream, B, T, D):
+    out = torch.empty(D, dtype=torch.float32, device=stream.device)
+    L.call('p4p_cls_rows', L.ptr(stream), L.ptr(out), B, T, D, 0, _stream())
+    return out
+
+
+def colreduce(part, nrows, ncols):
+    out = torch.empty(ncols, dtype=torch.float32, device=part.device)
+    L.call('p4p_colreduce_f32', L.ptr(part), L.ptr(out), int(nrows), L.i64(ncols), int(ncols), 0.0, _stream())
+    return out
+
+
+# ---------------------------------------------------------------- P3Embed local MLP
+def embed_partial_rows():
+    return L.call_int('p4p_embed_partial_rows')
+
+
+def embed_moments(points, feats, idx):
+    B, N, _ = points.shape
+    _, S, k = idx.shape
+    part = torch.empty(embed_partial_rows(), 27, dtype=torch.float32, device=points.device)
+    L.call('p4p_embed_moments', L.ptr(points), L.ptr(feats), L.ptr(idx), L.ptr(part), B, N, S, k, _stream())
+    return part
+
+
+def embed_fold(W1, W2, b2, bn, mom_partial, Np, training):
+    C1 = W2.shape[0]
+    dev = W1.device
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    aeff, scale, shift, mean, invstd, mom = f(C1, 8), f(C1), f(C1), f(C1), f(C1), f(42)
+    L.call('p4p_embed_fold', L.ptr(W1), L.ptr(W2), L.ptr(b2), L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean),
+           L.ptr(bn.running_var), L.ptr(mom_partial), L.ptr(aeff), L.ptr(scale), L.ptr(shift), L.ptr(mean),
+           L.ptr(invstd), L.ptr(mom), L.i64(Np), float(bn.eps), float(bn.momentum), int(training), C1, _stream())
+    return aeff, scale, shift, mean, invstd, mom
+
+
+def embed_stage1(points, feats, idx, aeff, scale, shift):
+    B, N, _ = points.shape
+    _, S, k = idx.shape
+    C1 = aeff.shape[0]
+    dev = points.device
+    F1 = torch.empty(B * S * k, C1, dtype=torch.bfloat16, device=dev)
+    pooled = torch.empty(B * S, C1, dtype=torch.bfloat16, device=dev)
+    arg = torch.empty(B * S, C1, dtype=torch.uint8, device=dev)
+    L.call('p4p_embed_stage1', L.ptr(points), L.ptr(feats), L.ptr(idx), L.ptr(aeff), L.ptr(scale), L.ptr(shift),
+           L.ptr(F1), L.ptr(pooled), L.ptr(arg), B, N, S, k, C1, _stream())
+    return F1, pooled, arg
+
+
+def bn_finalize(sums, bn, Np, training):
+    C = bn.weight.shape[0]
+    dev = bn.weight.device
+    f = lambda: torch.empty(C, dtype=torch.float32, device=dev)
+    scale, shift, mean, invstd = f(), f(), f(), f()
+    L.call('p4p_bn_finalize', L.ptr(sums), L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean),
+           L.ptr(bn.running_var), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.i64(Np), float(bn.eps),
+           float(bn.momentum), int(training), C, _stream())
+    return scale, shift, mean, invstd
+
+
+def bn_relu(x, scale, shift):
+    y = torch.empty_like(x)
+    L.call('p4p_bn_relu_bf16', L.ptr(x), L.ptr(y), L.ptr(scale), L.ptr(shift), L.i64(x.shape[0]), x.shape[1], _stream())
+    return y
+
+
+def bn_relu_maxpool(H3, scale, shift, G, k, want_arg=True):
+    C = H3.shape[1]
+    tok = torch.empty(G, C, dtype=torch.float32, device=H3.device)
+    arg = torch.empty(G, C, dtype=torch.uint8, device=H3.device) if want_arg else None
+    L.call('p4p_bn_relu_maxpool', L.ptr(H3), L.ptr(scale), L.ptr(shift), None, L.ptr(tok), L.ptr(arg), L.i64(G), k, C,
+           _stream())
+    return tok, arg
+
+
+def pool_bn_bwd(dtok, H3, arg, scale, shift, mean, invstd, G, k):
+    C = H3.shape[1]
+    part = _workspace('embed_part', embed_partial_rows() * 7 * 512, H3.device)
+    sums = torch.empty(2, C, dtype=torch.float32, device=H3.device)
+    dH3 = torch.empty_like(H3)
+    L.call('p4p_pool_bn_bwd', L.ptr(dtok), int(dtok.dtype == torch.float32), L.ptr(H3), L.ptr(arg), L.ptr(scale),
+           L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.ptr(part), L.ptr(sums), L.ptr(dH3), L.i64(G), k, C, _stream())
+    return dH3, sums
+
+
+def relu_bn_bwd_(dY, H, scale, shift, mean, invstd):
+    rows, C = H.shape
+    part = _workspace('embed_part', embed_partial_rows() * 7 * 512, H.device)
+    sums = torch.empty(2, C, dtype=torch.float32, device=H.device)
+    L.call('p4p_relu_bn_bwd', L.ptr(dY), L.ptr(H), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.ptr(part),
+           L.ptr(sums), L.i64(rows), C, _stream())
+    return sums
+
+
+def group_sum(x, G, k):
+    out = torch.empty(G, x.shape[1], dtype=torch.bfloat16, device=x.device)
+    L.call('p4p_group_sum_bf16', L.ptr(x), L.ptr(out), L.i64(G), k, x.shape[1], _stream())
+    return out
+
+
+def embed_stage1_bwd(points, feats, idx, F1, dF1, dPooled, arg, mom, aeff, W1, W2, gamma, invstd):
+    B, N, _ = points.shape
+    _, S, k = idx.shape
+    C1 = aeff.shape[0]
+    dev = points.device
+    part = _workspace('embed_part', embed_partial_rows() * 7 * 512, dev)
+    sums = torch.empty(7, C1, dtype=torch.float32, device=dev)
+    f = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    dW1, dW2, db2, dg, db = f(C1, 6), f(C1, C1), f(C1), f(C1), f(C1)
+    L.call('p4p_embed_stage1_bwd', L.ptr(points), L.ptr(feats), L.ptr(idx), L.ptr(F1), L.ptr(dF1), L.ptr(dPooled),
+           L.ptr(arg), L.ptr(part), L.ptr(sums), L.ptr(mom), L.ptr(aeff), L.ptr(W1), L.ptr(W2), L.ptr(gamma),
+           L.ptr(invstd), L.ptr(dW1), L.ptr(dW2), L.ptr(db2), L.ptr(dg), L.ptr(db), 0.0, B, N, S, k, C1, _stream())
+    return dW1, dW2, db2, dg, db

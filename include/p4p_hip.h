@@ -67,10 +67,12 @@ int p4p_wgrad_splits(int M, int N, int K);
 int p4p_layernorm_fwd(const float* x, const float* pos, const float* gamma, const float* beta, float eps,
                       float* xsum, void* y, int y_is_f32, float* mean, float* rstd, int M, int D, void* stream);
 /* dx = (accumulate_dx ? dx : 0) + LN'(dy); dgamma/dbeta = beta_acc*old + sums (either may be NULL).
+ * dx_bf16 (may be NULL) receives a bf16 copy of dx (next GEMM operand); dacc (may be NULL) accumulates dx
+ * (gradient of the positional embedding that is re-added before every block, pix4point.py:255).
  * partial: [p4p_layernorm_bwd_partial_rows()][2][D] f32 workspace. */
 int p4p_layernorm_bwd(const void* dy, int dy_is_f32, const float* xin, const float* mean, const float* rstd,
-                      const float* gamma, float* dx, int accumulate_dx, float* partial, float* dgamma, float* dbeta,
-                      float beta_acc, int M, int D, void* stream);
+                      const float* gamma, float* dx, int accumulate_dx, void* dx_bf16, float* dacc, int dacc_init,
+                      float* partial, float* dgamma, float* dbeta, float beta_acc, int M, int D, void* stream);
 int p4p_layernorm_bwd_partial_rows(void);
 int p4p_colreduce_f32(const float* part, float* out, int nrows, long long stride, int ncols, float beta, void* stream);
 
@@ -81,6 +83,59 @@ int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B, int T, int
 /* dqkv [B*T,3D] bf16 <- gradients; delta [B,H,T] f32 workspace. */
 int p4p_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse2, float* delta, void* dqkv,
                       int B, int T, int H, int D, float scale, void* stream);
+
+/* ---- streaming helpers ----------------------------------------------------------------------------- */
+
+/* fp32 master weight [R,C] (row stride ld_src) -> bf16 copies dst [R,C] and dstT [C,R] (either may be NULL). */
+int p4p_cast_transpose_f32_bf16(const float* src, long long ld_src, void* dst, void* dstT, int R, int C, void* stream);
+int p4p_cast_f32_bf16(const float* src, void* dst, long long n, void* stream);
+/* out[N] = beta*out + column sums of G[M,N] bf16 (autograd of nn.Linear.bias). workspace: p4p_colsum_splits(M)*N f32 */
+int p4p_colsum_bf16(const void* G, float* out, float* workspace, int M, int N, float beta, void* stream);
+int p4p_colsum_splits(int M);
+/* token stream [B,T=S+1,D] f32 <-> compact patch rows [B*S,D] (cls row first, pix4point.py:248-252).
+ * mode 0: compact(bf16) = stream rows; mode 1: stream rows = compact(f32). */
+int p4p_token_rows(float* stream_f32, void* compact, int B, int S, int D, int mode, void* stream);
+/* mode 1: stream[b,0,:] = vec; mode 0: vec = sum_b stream[b,0,:] */
+int p4p_cls_rows(float* stream_f32, float* vec, int B, int T, int D, int mode, void* stream);
+
+/* ---- P3Embed local MLP (src/models/pix4point.py:137-156,178-188); see csrc/embed.hip for the algebra ---- */
+
+int p4p_embed_partial_rows(void);
+/* partial [p4p_embed_partial_rows()][27]: sums and upper-triangular second moments of x6 = [xyz, feats][idx] */
+int p4p_embed_moments(const float* points, const float* feats, const int32_t* idx, float* partial, int B, int N, int S,
+                      int k, void* stream);
+/* folds convs[0][0], convs[0][1], BatchNorm2d into f1 = relu(scale * (aeff . x6) + shift); updates the running
+ * statistics in training mode.  aeff [C1,8], mom [42]. */
+int p4p_embed_fold(const float* W1, const float* W2, const float* b2, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, const float* mom_partial, float* aeff, float* scale,
+                   float* shift, float* save_mean, float* save_invstd, float* mom, long long Np, float eps,
+                   float momentum, int training, int C1, void* stream);
+/* F1 [B*S*k,C1] bf16, pooled [B*S,C1] bf16 (= max_k, pix4point.py:163,185), arg [B*S,C1] u8 */
+int p4p_embed_stage1(const float* points, const float* feats, const int32_t* idx, const float* aeff,
+                     const float* scale, const float* shift, void* F1, void* pooled, uint8_t* arg, int B, int N, int S,
+                     int k, int C1, void* stream);
+/* BatchNorm scale/shift from column sums [2][C] (training) or running statistics (eval) */
+int p4p_bn_finalize(const float* sums, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    float* scale, float* shift, float* save_mean, float* save_invstd, long long Np, float eps,
+                    float momentum, int training, int C, void* stream);
+int p4p_bn_relu_bf16(const void* x, void* y, const float* scale, const float* shift, long long rows, int C, void* stream);
+/* tokens[g,c] = max_j relu(scale*H3[g*k+j,c]+shift) (pix4point.py:188) */
+int p4p_bn_relu_maxpool(const void* H3, const float* scale, const float* shift, void* tok_bf16, float* tok_f32,
+                        uint8_t* arg, long long G, int k, int C, void* stream);
+/* backward of max-pool + ReLU + BatchNorm: dH3 [G*k,C] bf16, sums[2][C] = (sum dy, sum dy*xhat) = (dbeta, dgamma) */
+int p4p_pool_bn_bwd(const void* dtok, int dtok_is_f32, const void* H3, const uint8_t* arg, const float* scale,
+                    const float* shift, const float* mean, const float* invstd, float* partial, float* sums, void* dH3,
+                    long long G, int k, int C, void* stream);
+/* backward of ReLU + BatchNorm on a dense gradient, in place over dY; sums as above */
+int p4p_relu_bn_bwd(void* dY, const void* H, const float* scale, const float* shift, const float* mean,
+                    const float* invstd, float* partial, float* sums, long long rows, int C, void* stream);
+int p4p_group_sum_bf16(const void* X, void* out, long long G, int k, int C, void* stream);
+/* backward of stage 1 (ReLU, BatchNorm, both leading convs) in closed form from sum(dy), sum(dy (x) x6) */
+int p4p_embed_stage1_bwd(const float* points, const float* feats, const int32_t* idx, const void* F1, const void* dF1,
+                         const void* dPooled, const uint8_t* arg, float* partial, float* sums, const float* mom,
+                         const float* aeff, const float* W1, const float* W2, const float* gamma,
+                         const float* save_invstd, float* dW1, float* dW2, float* db2, float* dgamma, float* dbeta,
+                         float beta_acc, int B, int N, int S, int k, int C1, void* stream);
 
 #ifdef __cplusplus
 }

@@ -50,13 +50,14 @@ def farthest_point_sampling(points: torch.Tensor, n_samples: int,
     """
     B, N, _ = points.shape
     n = min(int(n_samples), N)                                   # :23
-    picked = torch.zeros(B, n, dtype=torch.long)                 # :26
-    running = torch.ones(B, N, dtype=points.dtype) * 1e10        # :27
+    dev = points.device
+    picked = torch.zeros(B, n, dtype=torch.long, device=dev)     # :26
+    running = torch.ones(B, N, dtype=points.dtype, device=dev) * 1e10   # :27
     if start_idx is None:
-        far = torch.randint(0, N, (B,), dtype=torch.long)        # :30
+        far = torch.randint(0, N, (B,), dtype=torch.long, device=dev)   # :30
     else:
         far = start_idx.to(torch.long).clone()
-    rows = torch.arange(B)
+    rows = torch.arange(B, device=dev)
     for i in range(n):
         picked[:, i] = far                                       # :37
         c = points[rows, far, :].view(B, 1, -1)                  # :40-41
@@ -136,7 +137,7 @@ def group_knn(pnts: torch.Tensor, cntrds: torch.Tensor, feats: torch.Tensor, k: 
     if idx is None:
         idx = knn_indices(cntrds, pnts, k)
     B = pnts.shape[0]
-    b = torch.arange(B).view(B, 1, 1).expand(-1, idx.shape[1], idx.shape[2])   # :94-98
+    b = torch.arange(B, device=pnts.device).view(B, 1, 1).expand(-1, idx.shape[1], idx.shape[2])   # :94-98
     li = idx.long()
     return pnts[b, li], feats[b, li]                                          # :99-100
 
