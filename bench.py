@@ -1,0 +1,240 @@
+"""Contract benchmark: point-clouds/sec of one Pix4Point training step on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): ModelNet40-shaped synthetic clouds N=1024, Pix4Point ViT-B/12
+(D=768, H=12), k=16, batch 256 per GPU, random-init weights, bf16 MFMA operands / fp32 accumulate.
+A step = zero_grad + forward + cross-entropy + backward (+ RCCL gradient all-reduce when N>1) +
+clip_grad_norm_ + AdamW, i.e. reference src/train/pix4point_trainer.py:162-167, inputs resident in HBM.
+One JSON line on rank 0; `roofline` is measured in a separate instrumented pass after the timed region
+(HIP events around every MFMA GEMM launch on the launch stream); `cpu_baseline` times the CPU oracle
+(fp32 torch restatement of the reference) on the host cores for a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md)
+FLOP_PER_CLOUD = {1024: 149.6e9, 2048: 313.2e9}     # fwd+bwd algorithmic FLOPs, SURVEY.md section 8d
+
+
+def synthetic_batch(B, N, num_classes, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    p = torch.rand(B, N, 3, generator=g) * 2 - 1
+    p = p - p.mean(dim=1, keepdim=True)
+    p = p / p.norm(dim=2).max(dim=1).values.view(B, 1, 1)
+    labels = torch.randint(0, num_classes, (B,), generator=g)
+    start = torch.randint(0, N, (B,), generator=g)
+    return p.contiguous().to(device), labels.to(device), start.to(device)
+
+
+class Stepper:
+    def __init__(self, args, device, distributed):
+        import p4p_amd
+        from p4p_amd.ddp import broadcast_parameters, build_reducer
+        torch.manual_seed(1234)
+        self.model = p4p_amd.Pix4Point(num_classes=args.classes, embed_dim=args.dim, pretrained_model=args.vit,
+                                       pretrained=False, k_neighbors=16).to(device)
+        self.model.train()
+        broadcast_parameters(self.model)
+        self.reducer = build_reducer(self.model) if distributed else None
+        self.opt = torch.optim.AdamW(self.model.get_param_groups(), lr=5e-4, weight_decay=5e-2, fused=True)
+        self.crit = torch.nn.CrossEntropyLoss()
+
+    def step(self, pts, labels, start):
+        if self.reducer is not None:
+            self.reducer.zero_grad()
+        else:
+            self.opt.zero_grad(set_to_none=True)
+        loss = self.crit(self.model(pts, start), labels)
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=10, foreach=True)
+        self.opt.step()
+        return loss
+
+
+def instrumented_roofline(stepper, batch, steps):
+    """HIP events around every bf16 MFMA GEMM launch (forward, dgrad: gemm_tn_kernel; wgrad:
+    gemm_wgrad_kernel) during `steps` extra training steps; algorithmic FLOPs = 2 M N K per launch."""
+    from p4p_amd import ops
+    rec = []
+    orig_tn, orig_wg = ops.gemm_tn, ops.gemm_wgrad
+
+    def tn(a, w, epilogue=ops.EPI_BF16, **kw):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = orig_tn(a, w, epilogue, **kw)
+        e.record()
+        rec.append((f'gemm_tn_kernel<{epilogue}>', 2.0 * a.shape[0] * w.shape[0] * a.shape[1], s, e))
+        return out
+
+    def wg(g, a, **kw):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = orig_wg(g, a, **kw)
+        e.record()
+        rec.append(('gemm_wgrad_kernel', 2.0 * g.shape[0] * g.shape[1] * a.shape[1], s, e))
+        return out
+
+    ops.gemm_tn, ops.gemm_wgrad = tn, wg
+    try:
+        for _ in range(steps):
+            stepper.step(*batch)
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm_tn, ops.gemm_wgrad = orig_tn, orig_wg
+    agg = {}
+    for name, fl, s, e in rec:
+        a = agg.setdefault(name, [0.0, 0.0, 0])
+        a[0] += fl
+        a[1] += s.elapsed_time(e) * 1e-3
+        a[2] += 1
+    dom = max(agg, key=lambda k: agg[k][1])
+    fl, t, n = agg[dom]
+    all_fl, all_t = sum(v[0] for v in agg.values()), sum(v[1] for v in agg.values())
+    return {
+        'bound': 'mfma', 'kernel': dom, 'achieved': fl / t * 1e-12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+        'frac': fl / t * 1e-12 / PEAK_BF16_TFLOPS, 'traffic': None,
+        'avg_launch_us': t / n * 1e6, 'launches_per_step': n / steps, 'flop_per_launch': fl / n,
+        'all_mfma_gemms': {'achieved': all_fl / all_t * 1e-12, 'frac': all_fl / all_t * 1e-12 / PEAK_BF16_TFLOPS,
+                           'time_per_step_ms': all_t / steps * 1e3},
+        'per_kernel': {k: {'TFLOP/s': v[0] / v[1] * 1e-12, 'ms_per_step': v[1] / steps * 1e3, 'launches': v[2] // steps}
+                       for k, v in sorted(agg.items())},
+    }
+
+
+def cpu_baseline(args, budget_s=25.0):
+    """The CPU oracle (pure-torch fp32 restatement of the reference path) doing the same training step on the
+    host cores, on a bounded sample: batch 8 of the same synthetic clouds, as many steps as fit the budget."""
+    from oracle import pix4point_oracle as O
+    from p4p_amd.vit import parse_model_name
+    D, L, H, _, _ = parse_model_name(args.vit)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = O.Pix4Point(num_classes=args.classes, embed_dim=D, depth=L, heads=H)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=5e-2)
+    B = 8
+    pts, labels, start = synthetic_batch(B, args.points, args.classes, 99, 'cpu')
+
+    def one():
+        opt.zero_grad()
+        loss = torch.nn.functional.cross_entropy(model(pts, start), labels)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 10)
+        opt.step()
+    one()                                   # warm-up (allocator, thread pool)
+    t0, n = time.perf_counter(), 0
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 8:
+            break
+    return {'value': B * n / el, 'unit': 'point-clouds/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'{n} train steps of batch {B} (N={args.points}, {args.vit}, fp32 torch CPU oracle)',
+            'torch_threads': torch.get_num_threads()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=256, help='clouds per GPU')
+    ap.add_argument('--points', type=int, default=1024)
+    ap.add_argument('--vit', default='vit_base_patch16_384')
+    ap.add_argument('--dim', type=int, default=768)
+    ap.add_argument('--classes', type=int, default=40)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+
+    stepper = Stepper(args, device, distributed)
+    batch = synthetic_batch(args.batch, args.points, args.classes, 1234 + rank, device)
+
+    for _ in range(args.warmup):
+        stepper.step(*batch)
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = stepper.step(*batch)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(loss)
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        roof = instrumented_roofline(stepper, batch, max(2, min(args.steps, 5)))
+    if distributed:
+        dist.barrier()
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        clouds = args.batch * world * args.steps
+        value = clouds / elapsed
+        fl = FLOP_PER_CLOUD.get(args.points)
+        out = {
+            'metric': f'point-clouds/sec fwd+bwd (train step), ModelNet40-shaped N={args.points} ViT-B',
+            'value': value, 'unit': 'point-clouds/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'Pix4Point {args.vit} (D={args.dim}, 12 blocks) N={args.points} k=16, '
+                                   f'{args.classes} classes, batch {args.batch}/GPU; step = zero_grad+fwd+CE+bwd'
+                                   f'{"+RCCL all-reduce" if distributed else ""}+clip_grad_norm+AdamW(fused)',
+                       'global_batch': args.batch * world, 'points': args.points, 'parallelism': f'dp{world}',
+                       'final_loss': loss_val},
+            'algorithmic_tflops_per_gpu': (value / world * fl * 1e-12) if fl else None,
+            'mfma_frac_whole_step': (value / world * fl * 1e-12 / PEAK_BF16_TFLOPS) if fl else None,
+        }
+        if roof:
+            out['roofline'] = roof
+        if cpu:
+            out['cpu_baseline'] = cpu
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

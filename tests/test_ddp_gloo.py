@@ -1,0 +1,95 @@
+"""CPU, world_size 2, gloo: the gradient exchange (ddp.GradReducer) used for the N>1 path.
+The HIP kernels are not involved (no GPU here); the reducer's bucketing, in-backward launches and
+averaging are exercised with a small torch model whose 'blocks' report their gradients the way the
+encoder's backward does."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from p4p_amd.ddp import GradReducer, broadcast_parameters
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)                 # different init per rank on purpose
+        blocks = torch.nn.ModuleList([torch.nn.Linear(8, 8) for _ in range(3)])
+        tail = torch.nn.Linear(8, 4)
+        unused = torch.nn.Linear(8, 8)                # never gets a gradient (quirk 8)
+        model = torch.nn.ModuleDict({'blocks': blocks, 'tail': tail, 'unused': unused})
+        broadcast_parameters(model)
+        w0 = [p.detach().clone() for p in model.parameters()]
+        gathered = [torch.zeros_like(w0[0]) for _ in range(world)]
+        dist.all_gather(gathered, w0[0])
+        assert all(torch.equal(g, gathered[0]) for g in gathered), 'broadcast_parameters failed'
+
+        buckets = [list(b.parameters()) for b in reversed(blocks)] + [list(tail.parameters())]
+        red = GradReducer(buckets)
+        for step in range(2):                         # two steps: zero_grad / reuse of the flat views
+            red.zero_grad()
+            x = torch.randn(5, 8, generator=torch.Generator().manual_seed(rank * 10 + step))
+            h = x
+            for b in blocks:
+                h = torch.tanh(b(h))
+            loss = tail(h).pow(2).mean()
+            params = [p for b in blocks for p in b.parameters()]
+            grads = torch.autograd.grad(loss, params + list(tail.parameters()))
+            local = [g.clone() for g in grads]
+            # "backward": blocks report last-to-first, the tail arrives through .grad accumulation
+            for l in reversed(range(3)):
+                ret = red.block_ready(l, list(blocks[l].parameters()), list(grads[2 * l:2 * l + 2]))
+                assert ret == [None, None]
+            for p, g in zip(tail.parameters(), grads[6:]):
+                p.grad.add_(g)                        # what AccumulateGrad does with an existing .grad
+            red.finish()
+            # reference: average of the per-rank local gradients
+            for p, g in zip(params + list(tail.parameters()), local):
+                both = [torch.zeros_like(g) for _ in range(world)]
+                dist.all_gather(both, g)
+                want = sum(both) / world
+                assert torch.allclose(p.grad, want, rtol=1e-6, atol=1e-7)
+                assert p.grad.data_ptr() >= red.flat.data_ptr()          # still a view of the flat buffer
+            assert all(p.grad is None for p in unused.parameters())
+        out.put((rank, 'ok'))
+    except Exception as e:                            # pragma: no cover
+        out.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_reducer_two_ranks_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, 'ok'), (1, 'ok')], res
+
+
+def test_grad_reducer_single_process_is_identity():
+    lin = torch.nn.Linear(4, 4)
+    red = GradReducer([list(lin.parameters())])
+    lin(torch.ones(2, 4)).sum().backward()
+    g = lin.weight.grad.clone()
+    red.finish()
+    assert torch.equal(lin.weight.grad, g)
+    red.zero_grad()
+    assert float(lin.weight.grad.abs().max()) == 0.0
