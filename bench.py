@@ -27,6 +27,33 @@ PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (guides/MI355X_MICROAR
 FLOP_PER_CLOUD = {1024: 149.6e9, 2048: 313.2e9}     # fwd+bwd algorithmic FLOPs, SURVEY.md section 8d
 
 
+def log(msg):
+    print(f'[bench] {msg}', file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box gives
+    one GPU's share of the host, not the whole machine)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, min(n, int(os.environ.get('P4P_CPU_THREADS', '16'))))
+
+
 def synthetic_batch(B, N, num_classes, seed, device):
     g = torch.Generator().manual_seed(seed)
     p = torch.rand(B, N, 3, generator=g) * 2 - 1
@@ -42,8 +69,10 @@ class Stepper:
         import p4p_amd
         from p4p_amd.ddp import broadcast_parameters, build_reducer
         torch.manual_seed(1234)
-        self.model = p4p_amd.Pix4Point(num_classes=args.classes, embed_dim=args.dim, pretrained_model=args.vit,
-                                       pretrained=False, k_neighbors=16).to(device)
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):      # the constructor prints (as the reference's does)
+            self.model = p4p_amd.Pix4Point(num_classes=args.classes, embed_dim=args.dim, pretrained_model=args.vit,
+                                           pretrained=False, k_neighbors=16).to(device)
         self.model.train()
         broadcast_parameters(self.model)
         self.reducer = build_reducer(self.model) if distributed else None
@@ -120,12 +149,9 @@ def cpu_baseline(args, budget_s=25.0):
     from oracle import pix4point_oracle as O
     from p4p_amd.vit import parse_model_name
     D, L, H, _, _ = parse_model_name(args.vit)
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = usable_cores()
     torch.set_num_threads(cores)
+    log(f'cpu_baseline: {cores} threads')
     torch.manual_seed(0)
     model = O.Pix4Point(num_classes=args.classes, embed_dim=D, depth=L, heads=H)
     model.train()
@@ -139,12 +165,15 @@ def cpu_baseline(args, budget_s=25.0):
         loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 10)
         opt.step()
+    tw = time.perf_counter()
     one()                                   # warm-up (allocator, thread pool)
+    log(f'cpu_baseline: warm-up step {time.perf_counter() - tw:.1f} s')
     t0, n = time.perf_counter(), 0
     while True:
         one()
         n += 1
         el = time.perf_counter() - t0
+        log(f'cpu_baseline: {n} steps in {el:.1f} s')
         if el > budget_s or n >= 8:
             break
     return {'value': B * n / el, 'unit': 'point-clouds/sec', 'cores': cores, 'kind': 'port',
@@ -181,6 +210,7 @@ def main():
     stepper = Stepper(args, device, distributed)
     batch = synthetic_batch(args.batch, args.points, args.classes, 1234 + rank, device)
 
+    log(f'rank {rank}/{world}: model built, warm-up {args.warmup} steps')
     for _ in range(args.warmup):
         stepper.step(*batch)
 
@@ -199,11 +229,13 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
+    log(f'timed region: {args.steps} steps in {elapsed:.3f} s')
 
     roof = None
     if rank == 0 and not args.no_roofline:
         roof = instrumented_roofline(stepper, batch, max(2, min(args.steps, 5)))
+        log('instrumented roofline pass done')
     if distributed:
         dist.barrier()
     cpu = None
