@@ -20,204 +20,64 @@
 // D lane l reg r -> D[4(l>>4)+r][l&15].  We pass the W (resp. A-matrix) fragment as the MFMA "A"
 // operand so each lane ends up with 4 CONSECUTIVE output columns of one output row: 8-B bf16 /
 // 16-B fp32 stores.
-#include "common.h"
+#include "gemm_tn.h"
+#include "gemm_tn3.h"
 
-#define BM 128
-#define BN 128
-#define BK 64
 #define GEMM_THREADS 256
 
 __device__ float g_zero_page[64];   // 256 B of zeros: LDS-DMA source for rows past the end (wgrad)
 
-enum {
-    EPI_BF16 = 0,          // out_bf16 = acc (+bias)
-    EPI_BF16_GELU = 1,     // pre_bf16 = acc+bias (if pre != null); out_bf16 = gelu(acc+bias)
-    EPI_F32_RESID = 2,     // out_f32 = acc (+bias) (+resid_f32)
-    EPI_BF16_DGELU = 3,    // out_bf16 = acc * gelu'(pre_bf16)
-    EPI_BF16_ROWGROUP = 4, // out_bf16 = acc + rowgrp_f32[m / group][n]; column sum / sumsq partials
-    EPI_BF16_STATS = 5,    // out_bf16 = acc (+bias); column sum / sumsq partials (BatchNorm statistics)
-};
+// tile configuration: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x128 (8 waves), 3 = 256x256 (8 waves),
+// 4 = 256x128 / 4 waves / K-step 32 / 3-stage ring (gemm_tn3.h); 11-13 = 1-3 with pinned scheduling
+static int g_gemm_variant = 0;
+extern "C" int p4p_set_gemm_variant(int v) { int o = g_gemm_variant; g_gemm_variant = v; return o; }
 
-struct GemmParams {
-    const __bf16* A;       // [M,K]
-    const __bf16* W;       // [N,K]
-    void* out;             // [M,N] bf16 or f32
-    const float* bias;     // [N] or null
-    const float* resid;    // [M,N] f32 or null       (EPI_F32_RESID)
-    __bf16* pre;           // [M,N] bf16 or null      (EPI_BF16_GELU writes, EPI_BF16_DGELU reads)
-    const float* rowgrp;   // [M/group, N] f32        (EPI_BF16_ROWGROUP)
-    float* stats;          // [tiles_m][2][N] f32 partial column sums / sums of squares
-    int M, N, K, group;
-};
-
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float dgelu_f(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
-}
-
-// XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
-// contiguous run of tiles; consecutive tiles sweep N for a fixed M panel (panel of A stays in that
-// XCD's L2, W is shared by everybody).  Bijective for any grid size.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-}
-
-// Stage one 128x64 bf16 tile (rows row0.., k-columns k0..k0+63) of a [rows,K] matrix into LDS.
-// wave w issues 4 LDS-DMA instructions of 8 rows each.
-__device__ __forceinline__ void stage_tile_tn(const __bf16* __restrict__ src, int nrows, int K, int row0, int k0,
-                                              char* lds_tile, int wave, int lane) {
-    const int rin = lane >> 3;                       // row inside the 8-row piece
-    const int chunk = (lane & 7) ^ rin;              // logical 16-B chunk this lane must fetch
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int piece = wave * 4 + q;
-        int r = row0 + piece * 8 + rin;
-        r = r < nrows ? r : nrows - 1;
-        const __bf16* g = src + (size_t)r * K + k0 + chunk * 8;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(lds_tile + piece * 1024), 16, 0, 0);
-    }
-}
-
-template <int EPI>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_tn_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * BM * BK * 2];   // [buf][A|W][16 KiB]
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int nk = p.K / BK;
-
-    f32x4 acc[4][4];     // [n-tile][m-tile]
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // per-lane fragment read offset inside a tile for k-step 0 (k-step 1 = offset ^ 64)
-    const int frag_off = (lane & 15) * 128 + ((((lane >> 4)) ^ (lane & 7)) << 4);
-
-    stage_tile_tn(p.A, p.M, p.K, m0, 0, lds, wave, lane);
-    stage_tile_tn(p.W, p.N, p.K, n0, 0, lds + BM * BK * 2, wave, lane);
-
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();                 // tile kt has landed (barrier drains LDS-DMA), buffer kt^1 is free
-        char* cur = lds + (kt & 1) * (2 * BM * BK * 2);
-        if (kt + 1 < nk) {
-            char* nxt = lds + ((kt + 1) & 1) * (2 * BM * BK * 2);
-            stage_tile_tn(p.A, p.M, p.K, m0, (kt + 1) * BK, nxt, wave, lane);
-            stage_tile_tn(p.W, p.N, p.K, n0, (kt + 1) * BK, nxt + BM * BK * 2, wave, lane);
-        }
-        const char* la = cur + (wm * 64) * 128;
-        const char* lw = cur + BM * BK * 2 + (wn * 64) * 128;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fa[4], fw[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fa[i] = *reinterpret_cast<const bf16x8*>(la + i * 16 * 128 + (frag_off ^ (ks << 6)));
-                fw[i] = *reinterpret_cast<const bf16x8*>(lw + i * 16 * 128 + (frag_off ^ (ks << 6)));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
-        }
-    }
-
-    // ---- epilogue: lane holds, for (i,j): row m = m0+wm*64+j*16+(lane&15), cols n..n+3 ----------
-    const int g = lane >> 4;
-    float csum[4][4], csq[4][4];
-    if (EPI == EPI_BF16_ROWGROUP || EPI == EPI_BF16_STATS) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) csum[i][r] = csq[i][r] = 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wn * 64 + i * 16 + g * 4;
-        const bool nok = n < p.N;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && nok) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 64 + j * 16 + (lane & 15);
-            if (!(nok && m < p.M)) continue;
-            const size_t o = (size_t)m * p.N + n;
-            f32x4 v = acc[i][j] + bv;
-            if (EPI == EPI_BF16) {
-                bf16x4 w = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                *reinterpret_cast<bf16x4*>((__bf16*)p.out + o) = w;
-            } else if (EPI == EPI_BF16_GELU) {
-                if (p.pre) {
-                    bf16x4 w = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                    *reinterpret_cast<bf16x4*>(p.pre + o) = w;
-                }
-                bf16x4 w = {f2bf(gelu_f(v[0])), f2bf(gelu_f(v[1])), f2bf(gelu_f(v[2])), f2bf(gelu_f(v[3]))};
-                *reinterpret_cast<bf16x4*>((__bf16*)p.out + o) = w;
-            } else if (EPI == EPI_F32_RESID) {
-                if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
-                *reinterpret_cast<f32x4*>((float*)p.out + o) = v;
-            } else if (EPI == EPI_BF16_DGELU) {
-                bf16x4 h = *reinterpret_cast<const bf16x4*>(p.pre + o);
-                bf16x4 w = {f2bf(v[0] * dgelu_f(bf2f(h[0]))), f2bf(v[1] * dgelu_f(bf2f(h[1]))),
-                            f2bf(v[2] * dgelu_f(bf2f(h[2]))), f2bf(v[3] * dgelu_f(bf2f(h[3])))};
-                *reinterpret_cast<bf16x4*>((__bf16*)p.out + o) = w;
-            } else {   // EPI_BF16_ROWGROUP / EPI_BF16_STATS
-                if (EPI == EPI_BF16_ROWGROUP)
-                    v += *reinterpret_cast<const f32x4*>(p.rowgrp + (size_t)(m / p.group) * p.N + n);
-                bf16x4 w = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                *reinterpret_cast<bf16x4*>((__bf16*)p.out + o) = w;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { csum[i][r] += v[r]; csq[i][r] += v[r] * v[r]; }
-            }
-        }
-    }
-    if (EPI == EPI_BF16_ROWGROUP || EPI == EPI_BF16_STATS) {
-        // reduce the 16 rows held across lanes (same g, lane&15 = 0..15) with DPP, then the two
-        // m-halves (wm) through LDS, and write one partial row per (tile_m) -- no atomics.
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(lds);           // [wm][2][128]
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float a = csum[i][r], b = csq[i][r];
-                a += dpp_f32<0xB1>(a); a += dpp_f32<0x4E>(a); a += dpp_f32<0x141>(a); a += dpp_f32<0x140>(a);
-                b += dpp_f32<0xB1>(b); b += dpp_f32<0x4E>(b); b += dpp_f32<0x141>(b); b += dpp_f32<0x140>(b);
-                if ((lane & 15) == 0) {
-                    int c = wn * 64 + i * 16 + g * 4 + r;
-                    red[(wm * 2 + 0) * 128 + c] = a;
-                    red[(wm * 2 + 1) * 128 + c] = b;
-                }
-            }
-        __syncthreads();
-        if (t < 128 && n0 + t < p.N) {
-            p.stats[((size_t)tm * 2 + 0) * p.N + n0 + t] = red[0 * 128 + t] + red[2 * 128 + t];
-            p.stats[((size_t)tm * 2 + 1) * p.N + n0 + t] = red[1 * 128 + t] + red[3 * 128 + t];
-        }
-    }
+template <int BM_, int BN_, int WAVES_M, int WAVES_N, int EPI, bool PIN = false>
+static int launch_cfg(const GemmParams& p, hipStream_t st) {
+    int tiles = ceil_div(p.M, BM_) * ceil_div(p.N, BN_);
+    hipLaunchKernelGGL((gemm_tn2_kernel<BM_, BN_, WAVES_M, WAVES_N, EPI, PIN>), dim3(tiles), dim3(WAVES_M * WAVES_N * 64), 0, st, p);
+    P4P_LAUNCH_CHECK();
+    return 0;
 }
 
 template <int EPI>
 static int launch_tn(const GemmParams& p, hipStream_t st) {
-    int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-    hipLaunchKernelGGL(gemm_tn_kernel<EPI>, dim3(tiles), dim3(GEMM_THREADS), 0, st, p);
-    P4P_LAUNCH_CHECK();
-    return 0;
+    constexpr bool STATS = EPI == EPI_BF16_ROWGROUP || EPI == EPI_BF16_STATS;
+    int v = g_gemm_variant;
+    if (STATS) v = 1;                         // statistics rows are per 128-row tile (p4p_gemm_tn_stats_rows)
+    if (v == 0) {
+        // measured on MI355X at the ViT-B shapes (tools/gemm_bench.py, random data):
+        //   plain bf16 epilogue  : 256x256 tile wins (940-1000 TFLOP/s vs 830 / 700)
+        //   GELU / fp32 residual / dGELU epilogues: the 2-workgroups-per-CU 256x128 ring overlaps the
+        //   HBM / VALU-heavy epilogue with the other workgroup's MFMA loop
+        const bool big = (long long)ceil_div(p.M, 256) * ceil_div(p.N, 128) >= 512;
+        if (EPI == EPI_BF16 && p.N % 256 == 0 && (long long)ceil_div(p.M, 256) * (p.N / 256) >= 256) v = 3;
+        else if (p.N % T3_BN == 0 && big) v = 4;
+        else v = 1;
+    }
+    if constexpr (!STATS) {
+        if (v == 4 && p.N % T3_BN == 0) {
+            int tiles = ceil_div(p.M, T3_BM) * (p.N / T3_BN);
+            hipLaunchKernelGGL(gemm_tn3_kernel<EPI>, dim3(tiles), dim3(T3_THREADS), 0, st, p);
+            P4P_LAUNCH_CHECK();
+            return 0;
+        }
+        if (v == 3) return launch_cfg<256, 256, 2, 4, EPI>(p, st);
+        if (v == 2) return launch_cfg<256, 128, 4, 2, EPI>(p, st);
+        if (v == 13) return launch_cfg<256, 256, 2, 4, EPI, true>(p, st);
+        if (v == 12) return launch_cfg<256, 128, 4, 2, EPI, true>(p, st);
+        if (v == 11) return launch_cfg<128, 128, 2, 2, EPI, true>(p, st);
+    }
+    return launch_cfg<128, 128, 2, 2, EPI>(p, st);
 }
 
 extern "C" int p4p_gemm_tn_bf16(int epi, const void* A, const void* W, void* out, const float* bias,
                                 const float* resid, void* pre, const float* rowgrp, float* stats, int M, int N,
                                 int K, int group, void* stream) {
     P4P_CHECK(A && W && out, "p4p_gemm_tn_bf16: null pointer");
-    P4P_CHECK(M >= 1 && N >= 4 && K >= BK, "p4p_gemm_tn_bf16: bad sizes M=%d N=%d K=%d", M, N, K);
-    P4P_CHECK(K % BK == 0, "p4p_gemm_tn_bf16: K=%d must be a multiple of %d", K, BK);
-    P4P_CHECK(N % 4 == 0, "p4p_gemm_tn_bf16: N=%d must be a multiple of 4", N);
+    P4P_CHECK(M >= 1 && N >= 8 && K >= 64, "p4p_gemm_tn_bf16: bad sizes M=%d N=%d K=%d", M, N, K);
+    P4P_CHECK(K % 64 == 0, "p4p_gemm_tn_bf16: K=%d must be a multiple of 64", K);
+    P4P_CHECK(N % 8 == 0, "p4p_gemm_tn_bf16: N=%d must be a multiple of 8", N);
     GemmParams p;
     p.A = (const __bf16*)A; p.W = (const __bf16*)W; p.out = out; p.bias = bias; p.resid = resid;
     p.pre = (__bf16*)pre; p.rowgrp = rowgrp; p.stats = stats; p.M = M; p.N = N; p.K = K; p.group = group;
@@ -239,7 +99,7 @@ extern "C" int p4p_gemm_tn_bf16(int epi, const void* A, const void* W, void* out
     P4P_CHECK(false, "p4p_gemm_tn_bf16: unknown epilogue %d", epi);
 }
 
-extern "C" int p4p_gemm_tn_stats_rows(int M) { return ceil_div(M, BM); }
+extern "C" int p4p_gemm_tn_stats_rows(int M) { return ceil_div(M, 128); }
 
 // ================================================================================================
 // Weight gradient: dW[N,K] = sum_m G[m,N]^T A[m,K].  grid = (tiles_n * tiles_k, splits); each split
@@ -279,6 +139,7 @@ struct WgradParams {
     const __bf16* G;   // [M,N]
     const __bf16* A;   // [M,K]
     float* out;        // [splits][N][K] slabs (or the final [N,K] when splits == 1)
+    float* bias_out;   // [splits][N] column sums of G (bias gradient) or null
     int M, N, K, splits, chunks_per_split;
 };
 
@@ -301,6 +162,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_wgrad_kernel(WgradParams
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bias gradient = G^T . 1: one extra MFMA per n-tile with an all-ones "A" fragment, only in the
+    // workgroups of the first k-tile column and the waves with wk == 0 (each G column counted once)
+    const bool do_bias = p.bias_out != nullptr && tk == 0 && wk == 0;
+    f32x4 accb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) accb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const __bf16 one = (__bf16)1.0f;
+    const bf16x8 ones = {one, one, one, one, one, one, one, one};
 
     // transposing read: lane (group g = l>>4, i = l&15) supplies row 8g + (i>>2) (+4 for the second
     // read), columns 4(i&3).. of the 16-column block; it receives column i of those 4 rows.
@@ -342,6 +211,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_wgrad_kernel(WgradParams
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fg[j], acc[i][j], 0, 0, 0);
+            if (do_bias) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fg[j], accb[j], 0, 0, 0);
+            }
+        }
+    }
+    if (do_bias && g == 0) {       // D[i][n] is the same for every i: lanes 0..15, register 0
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + li;
+            if (n < p.N) p.bias_out[(size_t)split * p.N + n] = accb[j][0];
         }
     }
     float* out = p.out + (size_t)split * p.N * p.K;
@@ -377,9 +258,9 @@ extern "C" int p4p_wgrad_splits(int M, int N, int K) {
     return want;
 }
 
-// workspace: splits*N*K floats (unused when splits == 1 and beta == 0)
-extern "C" int p4p_gemm_wgrad_bf16(const void* G, const void* A, float* dW, float* workspace, int M, int N, int K,
-                                   float beta, void* stream) {
+// workspace: splits*(N*K + N) floats.  dbias (may be null) = beta*dbias + column sums of G, from the same pass.
+extern "C" int p4p_gemm_wgrad_bf16(const void* G, const void* A, float* dW, float* dbias, float* workspace, int M, int N,
+                                   int K, float beta, void* stream) {
     P4P_CHECK(G && A && dW, "p4p_gemm_wgrad_bf16: null pointer");
     P4P_CHECK(M >= 1 && N >= 8 && K >= 8, "p4p_gemm_wgrad_bf16: bad sizes M=%d N=%d K=%d", M, N, K);
     P4P_CHECK(N % 8 == 0 && K % 8 == 0, "p4p_gemm_wgrad_bf16: N=%d and K=%d must be multiples of 8", N, K);
@@ -392,8 +273,9 @@ extern "C" int p4p_gemm_wgrad_bf16(const void* G, const void* A, float* dW, floa
     splits = ceil_div(chunks, p.chunks_per_split);
     p.splits = splits;
     bool direct = splits == 1 && beta == 0.f;
-    P4P_CHECK(direct || workspace, "p4p_gemm_wgrad_bf16: workspace required (splits=%d)", splits);
+    P4P_CHECK((direct && !dbias) || workspace, "p4p_gemm_wgrad_bf16: workspace required (splits=%d)", splits);
     p.out = direct ? dW : workspace;
+    p.bias_out = dbias ? workspace + (size_t)splits * N * K : nullptr;
     dim3 grid(ceil_div(N, 128) * ceil_div(K, 128), splits);
     hipLaunchKernelGGL(gemm_wgrad_kernel, grid, dim3(GEMM_THREADS), 0, st, p);
     P4P_LAUNCH_CHECK();
@@ -401,6 +283,11 @@ extern "C" int p4p_gemm_wgrad_bf16(const void* G, const void* A, float* dW, floa
         long long n = (long long)N * K;
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(n / 4, 256)), dim3(256), 0, st, workspace, dW, n,
                            splits, beta);
+        P4P_LAUNCH_CHECK();
+    }
+    if (dbias) {
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(N / 4, 256)), dim3(256), 0, st, p.bias_out, dbias,
+                           (long long)N, splits, beta);
         P4P_LAUNCH_CHECK();
     }
     return 0;

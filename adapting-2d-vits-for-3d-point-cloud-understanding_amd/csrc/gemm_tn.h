@@ -1,0 +1,239 @@
+// gemm_tn v2: C[M,N] = A[M,K] . W[N,K]^T on v_mfma_f32_16x16x32_bf16, templated on the block tile.
+//
+// Schedule ("mid-tile barrier"): fragments are double-buffered in REGISTERS one k-step ahead, and the
+// single barrier of a K-tile sits between its two k-steps:
+//
+//     A) issue ds_reads of (tile t, k-step 1)          | MFMAs on (tile t, k-step 0)   [already in regs]
+//     B) s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier       -> tile t+1 has landed, nobody reads buffer t&1 any more
+//     C) LDS-DMA tile t+2 -> buffer t&1; issue ds_reads of (tile t+1, k-step 0) | MFMAs on (tile t, k-step 1)
+//
+// so when the barrier releases every wave still has a full k-step of MFMAs whose operands are already in
+// registers: the matrix pipe does not drain at tile boundaries, and every LDS-DMA has a whole K-tile of
+// MFMA time to land.  LDS image and swizzle as in gemm.hip (128-B rows, chunk' = chunk ^ (row & 7)).
+//
+// Epilogue: bf16 outputs are staged through LDS (row stride BN*2+16 B) and written as full 16-B-per-lane
+// row segments; fp32 outputs are stored directly (16 B per lane).
+#pragma once
+#include "common.h"
+
+struct GemmParams {
+    const __bf16* A;       // [M,K]
+    const __bf16* W;       // [N,K]
+    void* out;             // [M,N] bf16 or f32
+    const float* bias;     // [N] or null
+    const float* resid;    // [M,N] f32 or null       (EPI_F32_RESID)
+    __bf16* pre;           // [M,N] bf16 or null      (EPI_BF16_GELU writes, EPI_BF16_DGELU reads)
+    const float* rowgrp;   // [M/group, N] f32        (EPI_BF16_ROWGROUP)
+    float* stats;          // [tiles_m][2][N] f32 partial column sums / sums of squares
+    int M, N, K, group;
+};
+
+enum {
+    EPI_BF16 = 0, EPI_BF16_GELU = 1, EPI_F32_RESID = 2, EPI_BF16_DGELU = 3, EPI_BF16_ROWGROUP = 4, EPI_BF16_STATS = 5,
+};
+
+// Exact-erf GELU (timm's nn.GELU) without libm's branchy erff: Phi(x) = 0.5(1+erf(x/sqrt2)) from
+// Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, i.e. fp32-level; outputs are rounded to bf16 anyway).
+// e = exp(-x^2/2) is shared between Phi and the density term of the derivative.
+__device__ __forceinline__ void phi_and_e(float x, float& Phi, float& e) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    e = __expf(-0.5f * x * x);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float half_tail = 0.5f * poly * e;              // 0.5 * erfc(z)
+    Phi = x >= 0.f ? 1.0f - half_tail : half_tail;
+}
+__device__ __forceinline__ float gelu_f(float x) { float P, e; phi_and_e(x, P, e); return x * P; }
+__device__ __forceinline__ float dgelu_f(float x) { float P, e; phi_and_e(x, P, e); return P + x * 0.3989422804014327f * e; }
+
+// XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
+// contiguous run of tiles; consecutive tiles sweep N for a fixed M panel.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+template <int BM_, int BN_, int WAVES_M, int WAVES_N, int EPI, bool PIN>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N * 64 * ((2 * (BM_ + BN_) * 128) > 81920 ? 1 : 2)) / 256)
+void gemm_tn2_kernel(GemmParams p) {
+    constexpr int NW = WAVES_M * WAVES_N, NT_ = NW * 64;
+    constexpr int WM_ = BM_ / WAVES_M, WN_ = BN_ / WAVES_N;       // per-wave tile
+    constexpr int MT = WM_ / 16, NTL = WN_ / 16;                 // 16x16 MFMA tiles per wave
+    constexpr int STAGE = (BM_ + BN_) * 128;                     // bytes per K-tile stage (BK = 64 bf16)
+    constexpr int PIECES = (BM_ + BN_) / 8;                      // 1-KiB LDS-DMA pieces per stage
+    constexpr int PPW = PIECES / NW;                             // pieces per wave
+    static_assert(PIECES % NW == 0, "pieces must divide evenly over waves");
+    constexpr int CSTRIDE = BN_ * 2 + 16;                        // epilogue staging row stride (bytes)
+    constexpr int LDS_BYTES = (2 * STAGE) > (BM_ * CSTRIDE) ? (2 * STAGE) : (BM_ * CSTRIDE);
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int tiles_n = (p.N + BN_ - 1) / BN_, tiles_m = (p.M + BM_ - 1) / BM_;
+    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM_, n0 = tn * BN_;
+    const int nk = p.K / 64;
+
+    // ---- LDS-DMA staging: piece q of the stage covers 8 rows; pieces [0, BM/8) are A rows, the rest W rows
+    const int rin = lane >> 3;
+    const int chunk = (lane & 7) ^ rin;
+    const __bf16* src[PPW];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int piece = wave * PPW + q;
+        const bool isA = piece < BM_ / 8;
+        int r = isA ? m0 + piece * 8 + rin : n0 + (piece - BM_ / 8) * 8 + rin;
+        const int lim = isA ? p.M : p.N;
+        r = r < lim ? r : lim - 1;
+        src[q] = (isA ? p.A : p.W) + (size_t)r * p.K + chunk * 8;
+    }
+    auto stage = [&](int kt, char* buf) {
+#pragma unroll
+        for (int q = 0; q < PPW; ++q)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src[q] + kt * 64), LDS_PTR(buf + (wave * PPW + q) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[NTL][MT];
+#pragma unroll
+    for (int i = 0; i < NTL; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frag_off = (lane & 15) * 128 + ((((lane >> 4)) ^ (lane & 7)) << 4);
+    const int a_base = wm * WM_ * 128 + frag_off;
+    const int w_base = BM_ * 128 + wn * WN_ * 128 + frag_off;
+    bf16x8 fa0[MT], fw0[NTL], fa1[MT], fw1[NTL];
+    auto read_frags = [&](const char* buf, int ks, bf16x8* fa, bf16x8* fw) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) fa[j] = *reinterpret_cast<const bf16x8*>(buf + ((a_base + j * 2048) ^ (ks << 6)));
+#pragma unroll
+        for (int i = 0; i < NTL; ++i) fw[i] = *reinterpret_cast<const bf16x8*>(buf + ((w_base + i * 2048) ^ (ks << 6)));
+    };
+    auto mma = [&](const bf16x8* fa, const bf16x8* fw) {
+#pragma unroll
+        for (int i = 0; i < NTL; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fa[j], acc[i][j], 0, 0, 0);
+    };
+
+    stage(0, lds);
+    __syncthreads();
+    if (nk > 1) stage(1, lds + STAGE);
+    read_frags(lds, 0, fa0, fw0);
+    for (int kt = 0; kt < nk; ++kt) {
+        char* cur = lds + (kt & 1) * STAGE;
+        char* nxt = lds + ((kt + 1) & 1) * STAGE;
+        read_frags(cur, 1, fa1, fw1);
+        if (PIN) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); }
+        mma(fa0, fw0);
+        if (PIN) { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); }
+        __syncthreads();                       // tile kt+1 landed everywhere; buffer `cur` is no longer read
+        if (kt + 2 < nk) stage(kt + 2, cur);
+        if (kt + 1 < nk) read_frags(nxt, 0, fa0, fw0);
+        if (PIN) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); }
+        mma(fa1, fw1);
+        if (PIN) { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); }
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // epilogue.  lane holds, for (i,j): row m = m0 + wm*WM + j*16 + (lane&15), cols n0 + wn*WN + i*16 + 4g .. +3
+    // ---------------------------------------------------------------------------------------------
+    const int g = lane >> 4, li = lane & 15;
+    constexpr bool BF16_OUT = EPI != EPI_F32_RESID;
+    constexpr bool STATS = EPI == EPI_BF16_ROWGROUP || EPI == EPI_BF16_STATS;
+    float csum[NTL][4], csq[NTL][4];
+    if (STATS) {
+#pragma unroll
+        for (int i = 0; i < NTL; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) csum[i][r] = csq[i][r] = 0.f;
+    }
+    if (BF16_OUT) __syncthreads();            // all waves are done with the operand buffers
+#pragma unroll
+    for (int i = 0; i < NTL; ++i) {
+        const int nl = wn * WN_ + i * 16 + g * 4;           // column inside the tile
+        const int n = n0 + nl;
+        const bool nok = n < p.N;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && nok) bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int ml = wm * WM_ + j * 16 + li;
+            const int m = m0 + ml;
+            const bool ok = nok && m < p.M;
+            const size_t o = (size_t)m * p.N + n;
+            f32x4 v = acc[i][j] + bv;
+            if (EPI == EPI_F32_RESID) {
+                if (ok) {
+                    if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
+                    *reinterpret_cast<f32x4*>((float*)p.out + o) = v;
+                }
+                continue;
+            }
+            if (EPI == EPI_BF16_GELU) {
+                // pre-activation goes out directly (it is only read back by the backward pass)
+                if (p.pre && ok) {
+                    bf16x4 w = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                    *reinterpret_cast<bf16x4*>(p.pre + o) = w;
+                }
+                v = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+            } else if (EPI == EPI_BF16_DGELU) {
+                if (ok) {
+                    bf16x4 h = *reinterpret_cast<const bf16x4*>(p.pre + o);
+                    v = f32x4{v[0] * dgelu_f(bf2f(h[0])), v[1] * dgelu_f(bf2f(h[1])), v[2] * dgelu_f(bf2f(h[2])),
+                              v[3] * dgelu_f(bf2f(h[3]))};
+                }
+            } else if (EPI == EPI_BF16_ROWGROUP) {
+                if (ok) v += *reinterpret_cast<const f32x4*>(p.rowgrp + (size_t)(m / p.group) * p.N + n);
+            }
+            if (STATS && ok) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { csum[i][r] += v[r]; csq[i][r] += v[r] * v[r]; }
+            }
+            bf16x4 w = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            *reinterpret_cast<bf16x4*>(lds + ml * CSTRIDE + nl * 2) = w;
+        }
+    }
+    if (BF16_OUT) {
+        __syncthreads();
+        constexpr int CPR = BN_ / 8;                        // 16-B chunks per tile row
+        for (int c = t; c < BM_ * CPR; c += NT_) {
+            const int ml = c / CPR, cc = c - ml * CPR;
+            const int m = m0 + ml, n = n0 + cc * 8;
+            if (m < p.M && n < p.N) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(lds + ml * CSTRIDE + cc * 16);
+                *reinterpret_cast<u32x4*>((__bf16*)p.out + (size_t)m * p.N + n) = v;
+            }
+        }
+    }
+    if (STATS) {
+        // 16 rows held across lanes of one DPP row -> reduce, then the WAVES_M row-waves through LDS
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(lds);           // [WAVES_M][2][BN]
+#pragma unroll
+        for (int i = 0; i < NTL; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = csum[i][r], b = csq[i][r];
+                a += dpp_f32<0xB1>(a); a += dpp_f32<0x4E>(a); a += dpp_f32<0x141>(a); a += dpp_f32<0x140>(a);
+                b += dpp_f32<0xB1>(b); b += dpp_f32<0x4E>(b); b += dpp_f32<0x141>(b); b += dpp_f32<0x140>(b);
+                if (li == 0) {
+                    const int c = wn * WN_ + i * 16 + g * 4 + r;
+                    red[(wm * 2 + 0) * BN_ + c] = a;
+                    red[(wm * 2 + 1) * BN_ + c] = b;
+                }
+            }
+        __syncthreads();
+        for (int c = t; c < BN_; c += NT_) {
+            if (n0 + c < p.N) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int w = 0; w < WAVES_M; ++w) { a += red[(w * 2 + 0) * BN_ + c]; b += red[(w * 2 + 1) * BN_ + c]; }
+                p.stats[((size_t)tm * 2 + 0) * p.N + n0 + c] = a;
+                p.stats[((size_t)tm * 2 + 1) * p.N + n0 + c] = b;
+            }
+        }
+    }
+}

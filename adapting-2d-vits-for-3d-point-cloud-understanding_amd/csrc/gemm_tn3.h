@@ -1,0 +1,249 @@
+// gemm_tn v3: C[M,N] = A[M,K] . W[N,K]^T, block tile 256 x 128, 4 waves each owning 128 x 64,
+// K-step 32, a 3-deep LDS-DMA ring with COUNTED vmcnt and a raw s_barrier, two workgroups per CU.
+//
+// Why this shape (gfx950): the per-wave tile sets the LDS read bytes per MFMA (12 KiB of ds_read_b128 per
+// 32 MFMAs = half of a 64x64 wave tile); 4 waves x ~245 VGPRs and 72 KiB of LDS let TWO workgroups share a
+// CU, so one workgroup's epilogue (HBM-bound: the outputs of these GEMMs are as large as their inputs)
+// overlaps the other's MFMA loop; the block tile keeps L2->LDS traffic at ~47 B/clk/CU at full MFMA rate.
+//
+// Pipeline invariant at the top of iteration t: fragments of K-step t are in registers, K-step t+1 has
+// landed in LDS and is barrier-published, K-step t+2 is in flight, ring slot t%3 is free.
+//     1) LDS-DMA K-step t+3 -> slot t%3
+//     2) ds_read fragments of K-step t+1 (other register set)
+//     3) 32 MFMAs on K-step t
+//     4) s_waitcnt vmcnt(PPW)  (everything but the PPW loads issued in 1) -> K-step t+2 landed);
+//        s_waitcnt lgkmcnt(0); s_barrier
+// Every load has two full iterations of MFMA time to land; the barrier never drains the load queue.
+//
+// LDS image per slot: [256 A rows | 128 W rows] x 64 B (32 bf16), 16-B chunk' = chunk ^ (((row>>2)&1)<<1):
+// conflict-free for the ds_read_b128 fragment reads (tools/lds_model.py).  LDS-DMA writes lane-linear, so
+// the swizzle is applied to the per-lane SOURCE address.
+#pragma once
+#include "gemm_tn.h"
+
+#define T3_BM 256
+#define T3_BN 128
+#define T3_THREADS 256
+#define T3_STAGE ((T3_BM + T3_BN) * 64)          // 24 KiB
+#define T3_PPW (((T3_BM + T3_BN) / 16) / 4)      // 1-KiB pieces per wave per stage = 6
+#define T3_LDS (3 * T3_STAGE)                    // 72 KiB
+// s_waitcnt immediates (gfx9 encoding: vmcnt[3:0]|[15:14], expcnt[6:4], lgkmcnt[11:8]); the BUILTIN keeps
+// hipcc's own wait-count bookkeeping in sync (it cannot see through inline asm)
+#define WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+#define WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
+
+struct T3Frags {
+    bf16x8 a[8];
+    bf16x8 w[4];
+};
+
+template <int EPI>
+__global__ __launch_bounds__(T3_THREADS, 2) void gemm_tn3_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(1024))) char lds[T3_LDS];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = p.N / T3_BN, tiles_m = (p.M + T3_BM - 1) / T3_BM;
+    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * T3_BM, n0 = tn * T3_BN;
+    const int nk = p.K / 32;
+
+    // ---- staging: piece = 16 rows x 64 B; pieces [0,16) are A rows, [16,24) are W rows
+    const int rin = lane >> 2;
+    const int chunk = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+    const __bf16* src[T3_PPW];
+#pragma unroll
+    for (int q = 0; q < T3_PPW; ++q) {
+        const int piece = wave * T3_PPW + q;
+        const bool isA = piece < T3_BM / 16;
+        int r = isA ? m0 + piece * 16 + rin : n0 + (piece - T3_BM / 16) * 16 + rin;
+        const int lim = isA ? p.M : p.N;
+        r = r < lim ? r : lim - 1;
+        src[q] = (isA ? p.A : p.W) + (size_t)r * p.K + chunk * 8;
+    }
+    auto stage = [&](int kt, char* buf) {
+#pragma unroll
+        for (int q = 0; q < T3_PPW; ++q)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src[q] + kt * 32), LDS_PTR(buf + (wave * T3_PPW + q) * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[4][8];     // [n-tile][m-tile]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int li = lane & 15, g = lane >> 4;
+    const int frag_off = li * 64 + ((g ^ (((li >> 2) & 1) << 1)) << 4);
+    const int a_off = wm * 128 * 64 + frag_off;
+    const int w_off = T3_BM * 64 + wn * 64 * 64 + frag_off;
+    auto read_frags = [&](const char* buf, T3Frags& f) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f.a[j] = *reinterpret_cast<const bf16x8*>(buf + a_off + j * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f.w[i] = *reinterpret_cast<const bf16x8*>(buf + w_off + i * 1024);
+    };
+    auto mma = [&](const T3Frags& f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.w[i], f.a[j], acc[i][j], 0, 0, 0);
+    };
+
+    char* s0 = lds;
+    char* s1 = lds + T3_STAGE;
+    char* s2 = lds + 2 * T3_STAGE;
+    T3Frags f0, f1;
+
+    // ---- prologue: three K-steps in flight, publish K-step 0 and 1
+    stage(0, s0);
+    if (nk > 1) stage(1, s1);
+    if (nk > 2) stage(2, s2);
+    if (nk > 2) WAIT_VM(2 * T3_PPW);
+    else if (nk > 1) WAIT_VM(T3_PPW);
+    else WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    read_frags(s0, f0);
+    if (nk > 2) WAIT_VM(T3_PPW);
+    else WAIT_VM(0);
+    WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();
+
+    // ring slots: cur holds K-step kt (already in registers: free), nxt holds kt+1, nn holds kt+2
+    char *cur = s0, *nxt = s1, *nn = s2;
+#define T3_ITER(FC, FN)                                                                   \
+    {                                                                                     \
+        const bool more3 = kt + 3 < nk;                                                   \
+        if (more3) stage(kt + 3, cur);                                                    \
+        if (kt + 1 < nk) read_frags(nxt, FN);                                             \
+        mma(FC);                                                                          \
+        if (kt + 1 < nk) {                                                                \
+            if (more3) WAIT_VM(T3_PPW);      \
+            else WAIT_VM(0);                         \
+            WAIT_LGKM0();                            \
+            __builtin_amdgcn_s_barrier();                                                 \
+        }                                                                                 \
+        char* tmp = cur; cur = nxt; nxt = nn; nn = tmp;                                   \
+    }
+    // steady state (K-steps kt, kt+1 with kt+4 < nk): no conditionals, so hipcc keeps the issue order
+    // {LDS-DMA, fragment prefetch, 32 MFMAs, counted wait, barrier} without conservative waits
+#define T3_FULL(KT, FC, FN)                                                               \
+    {                                                                                     \
+        stage((KT) + 3, cur);                                                             \
+        read_frags(nxt, FN);                                                              \
+        __builtin_amdgcn_sched_barrier(0);   /* keep the prefetch AHEAD of the MFMAs */   \
+        mma(FC);                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        WAIT_VM(T3_PPW);                                                                  \
+        WAIT_LGKM0();                                                                     \
+        __builtin_amdgcn_s_barrier();                                                     \
+        char* tmp = cur; cur = nxt; nxt = nn; nn = tmp;                                   \
+    }
+    int kt = 0;
+    for (; kt + 4 < nk; kt += 2) {
+        T3_FULL(kt, f0, f1)
+        T3_FULL(kt + 1, f1, f0)
+    }
+#undef T3_FULL
+    for (; kt < nk; kt += 2) {                 // tail: at most 4 K-steps, f0 holds an even K-step
+        T3_ITER(f0, f1)
+        ++kt;
+        if (kt < nk) T3_ITER(f1, f0)
+        --kt;
+    }
+#undef T3_ITER
+
+    // =============================================================================================
+    // epilogue: everything goes through LDS so that global traffic is 16 B per lane on full rows
+    // lane holds, for (i,j): row ml = wm*128 + j*16 + li, cols nl = wn*64 + i*16 + 4g .. +3
+    // =============================================================================================
+    __syncthreads();
+    constexpr int CS16 = T3_BN * 2 + 16;              // bf16 staging row stride (272 B)
+    constexpr int CS32 = T3_BN * 4 + 16;              // fp32 staging row stride (528 B)
+    f32x4 bias4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bias4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias4[i] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 64 + i * 16 + g * 4);
+    }
+
+    if (EPI == EPI_F32_RESID) {
+        // two passes of 128 rows (the rows of wave-row `pass`): fp32 tile 128 x 128 through LDS
+        for (int pass = 0; pass < 2; ++pass) {
+            if (wm == pass) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        *reinterpret_cast<f32x4*>(lds + (j * 16 + li) * CS32 + (wn * 64 + i * 16 + g * 4) * 4) =
+                            acc[i][j] + bias4[i];
+            }
+            __syncthreads();
+            for (int c = t; c < 128 * 32; c += T3_THREADS) {
+                const int rl = c >> 5, cc = c & 31;
+                const int m = m0 + pass * 128 + rl;
+                if (m < p.M) {
+                    const size_t o = (size_t)m * p.N + n0 + cc * 4;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(lds + rl * CS32 + cc * 16);
+                    if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
+                    *reinterpret_cast<f32x4*>((float*)p.out + o) = v;
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // bf16 outputs: copy the whole 256 x 128 tile between LDS and global with 16-B chunks (16 per row)
+    auto copy_out = [&](__bf16* dst) {
+        for (int c = t; c < T3_BM * 16; c += T3_THREADS) {
+            const int rl = c >> 4, cc = c & 15;
+            const int m = m0 + rl;
+            if (m < p.M)
+                *reinterpret_cast<u32x4*>(dst + (size_t)m * p.N + n0 + cc * 8) =
+                    *reinterpret_cast<const u32x4*>(lds + rl * CS16 + cc * 16);
+        }
+    };
+    if (EPI == EPI_BF16_DGELU) {
+        for (int c = t; c < T3_BM * 16; c += T3_THREADS) {         // pre-activation tile -> LDS, coalesced
+            const int rl = c >> 4, cc = c & 15;
+            int m = m0 + rl;
+            m = m < p.M ? m : p.M - 1;
+            *reinterpret_cast<u32x4*>(lds + rl * CS16 + cc * 16) =
+                *reinterpret_cast<const u32x4*>(p.pre + (size_t)m * p.N + n0 + cc * 8);
+        }
+        __syncthreads();
+    }
+    if (EPI == EPI_BF16_GELU && p.pre) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 v = acc[i][j] + bias4[i];
+                bf16x4 w = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                *reinterpret_cast<bf16x4*>(lds + (wm * 128 + j * 16 + li) * CS16 + (wn * 64 + i * 16 + g * 4) * 2) = w;
+            }
+        __syncthreads();
+        copy_out(p.pre);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            char* slot = lds + (wm * 128 + j * 16 + li) * CS16 + (wn * 64 + i * 16 + g * 4) * 2;
+            f32x4 v = acc[i][j] + bias4[i];
+            if (EPI == EPI_BF16_GELU) {
+                v = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+            } else if (EPI == EPI_BF16_DGELU) {
+                const bf16x4 h = *reinterpret_cast<const bf16x4*>(slot);
+                v = f32x4{v[0] * dgelu_f(bf2f(h[0])), v[1] * dgelu_f(bf2f(h[1])), v[2] * dgelu_f(bf2f(h[2])),
+                          v[3] * dgelu_f(bf2f(h[3]))};
+            }
+            bf16x4 w = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            *reinterpret_cast<bf16x4*>(slot) = w;
+        }
+    __syncthreads();
+    copy_out((__bf16*)p.out);
+}

@@ -151,25 +151,31 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(const void* _
     }
 }
 
-// out[c] = beta*out[c] + sum_r part[r*stride + c]   for c < ncols  (fixed order: reproducible)
-__global__ void colreduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nrows, long long stride,
-                                 int ncols, float beta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncols) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int r = 0;
-    for (; r + 3 < nrows; r += 4) {
-        s0 += part[(size_t)r * stride + c];
-        s1 += part[(size_t)(r + 1) * stride + c];
-        s2 += part[(size_t)(r + 2) * stride + c];
-        s3 += part[(size_t)(r + 3) * stride + c];
+// out[c] = beta*out[c] + sum_r part[r*stride + c]   for c < ncols  (fixed order: reproducible).
+// 256 threads = 32 columns x 8 row lanes; each lane strides the rows by 8, partials meet in LDS.
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                         int nrows, long long stride, int ncols, float beta) {
+    __shared__ float red[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < ncols) {
+        int r = ty;
+        for (; r + 8 < nrows; r += 16) {
+            s0 += part[(size_t)r * stride + c];
+            s1 += part[(size_t)(r + 8) * stride + c];
+        }
+        if (r < nrows) s0 += part[(size_t)r * stride + c];
     }
-    for (; r < nrows; ++r) s0 += part[(size_t)r * stride + c];
-    float s = (s0 + s1) + (s2 + s3);
-    out[c] = beta != 0.f ? beta * out[c] + s : s;
+    red[ty][tx] = s0 + s1;
+    __syncthreads();
+    if (ty == 0 && c < ncols) {
+        float s = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) + ((red[4][tx] + red[5][tx]) + (red[6][tx] + red[7][tx]));
+        out[c] = beta != 0.f ? beta * out[c] + s : s;
+    }
 }
 
-#define LN_BWD_BLOCKS 512
+#define LN_BWD_BLOCKS 1024
 
 extern "C" int p4p_layernorm_bwd_partial_rows(void) { return LN_BWD_BLOCKS; }
 
@@ -206,13 +212,19 @@ extern "C" int p4p_layernorm_bwd(const void* dy, int dy_is_f32, const float* xin
     if (J <= 1) LN_BWD(1); else if (J <= 2) LN_BWD(2); else if (J <= 3) LN_BWD(3); else if (J <= 4) LN_BWD(4); else LN_BWD(8);
 #undef LN_BWD
     P4P_LAUNCH_CHECK();
+    if (dgamma && dbeta == dgamma + D) {          // contiguous [2][D] destination: one launch
+        hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(2 * D, 32)), dim3(256), 0, st, partial, dgamma, blocks,
+                           (long long)2 * D, 2 * D, beta_acc);
+        P4P_LAUNCH_CHECK();
+        return 0;
+    }
     if (dgamma) {
-        hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(D, 256)), dim3(256), 0, st, partial, dgamma, blocks,
+        hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(D, 32)), dim3(256), 0, st, partial, dgamma, blocks,
                            (long long)2 * D, D, beta_acc);
         P4P_LAUNCH_CHECK();
     }
     if (dbeta) {
-        hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(D, 256)), dim3(256), 0, st, partial + D, dbeta, blocks,
+        hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(D, 32)), dim3(256), 0, st, partial + D, dbeta, blocks,
                            (long long)2 * D, D, beta_acc);
         P4P_LAUNCH_CHECK();
     }
@@ -222,7 +234,7 @@ extern "C" int p4p_layernorm_bwd(const void* dy, int dy_is_f32, const float* xin
 extern "C" int p4p_colreduce_f32(const float* part, float* out, int nrows, long long stride, int ncols, float beta,
                                  void* stream) {
     P4P_CHECK(part && out && nrows >= 1 && ncols >= 1, "p4p_colreduce_f32: bad arguments");
-    hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(ncols, 256)), dim3(256), 0, (hipStream_t)stream, part, out,
+    hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(ncols, 32)), dim3(256), 0, (hipStream_t)stream, part, out,
                        nrows, stride, ncols, beta);
     P4P_LAUNCH_CHECK();
     return 0;

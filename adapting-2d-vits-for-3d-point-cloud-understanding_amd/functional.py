@@ -125,9 +125,13 @@ class _LinearFn(torch.autograd.Function):
         dx = dW = db = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_tn(g, Wt, ops.EPI_F32_RESID).view(ctx.xshape)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dW = ops.gemm_wgrad(g, xb)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if want_b:
+                dW, db = ops.gemm_wgrad(g, xb, want_bias=True)
+            else:
+                dW = ops.gemm_wgrad(g, xb)
+        elif want_b:
             db = ops.colsum(g)
         return dx, dW, db
 
@@ -211,20 +215,20 @@ class _EncoderFn(torch.autograd.Function):
             _, Wfc1T = _bf16_weights(fc1w, True)
             dln2 = ops.gemm_tn(dh, Wfc1T, ops.EPI_BF16)
             if wg:
-                dfc2w, dfc2b = ops.gemm_wgrad(dxb, g), ops.colsum(dxb)
-                dfc1w, dfc1b = ops.gemm_wgrad(dh, ln2), ops.colsum(dh)
+                dfc2w, dfc2b = ops.gemm_wgrad(dxb, g, want_bias=True)
+                dfc1w, dfc1b = ops.gemm_wgrad(dh, ln2, want_bias=True)
             del dh
             _, dn2w, dn2b = ops.layernorm_bwd(dln2, x1, mean2, rstd2, n2w.detach(), dx=dx, dx_bf16=dxb)
             # ---- attention: x1 = xin + proj(attn(qkv(ln1)))
             _, WprojT = _bf16_weights(projw, True)
             datt = ops.gemm_tn(dxb, WprojT, ops.EPI_BF16)
             if wg:
-                dprojw, dprojb = ops.gemm_wgrad(dxb, att), ops.colsum(dxb)
+                dprojw, dprojb = ops.gemm_wgrad(dxb, att, want_bias=True)
             dqkv = ops.attention_bwd(qkv, att, datt, lse, B, T, H)
             _, WqkvT = _bf16_weights(qkvw, True)
             dln1 = ops.gemm_tn(dqkv, WqkvT, ops.EPI_BF16)
             if wg:
-                dqkvw, dqkvb = ops.gemm_wgrad(dqkv, ln1), ops.colsum(dqkv)
+                dqkvw, dqkvb = ops.gemm_wgrad(dqkv, ln1, want_bias=True)
             del dqkv, datt
             _, dn1w, dn1b = ops.layernorm_bwd(dln1, xin, mean1, rstd1, n1w.detach(), dx=dx, dx_bf16=dxb, dacc=dpos,
                                               dacc_init=(l == L - 1))

@@ -111,8 +111,9 @@ def _workspace(key, numel, device, dtype=torch.float32):
     return t
 
 
-def gemm_wgrad(g, a, out=None, beta=0.0):
-    """dW[N,K] f32 = beta*dW + g[M,N]^T @ a[M,K]."""
+def gemm_wgrad(g, a, out=None, beta=0.0, want_bias=False, bias_out=None):
+    """dW[N,K] f32 = beta*dW + g[M,N]^T @ a[M,K]; with want_bias also returns the column sums of g
+    (the bias gradient), produced by the same kernel."""
     _chk(g, 'g', torch.bfloat16, 2)
     _chk(a, 'a', torch.bfloat16, 2)
     M, N = g.shape
@@ -124,9 +125,13 @@ def gemm_wgrad(g, a, out=None, beta=0.0):
         beta = 0.0
     _chk(out, 'out', torch.float32, 2)
     splits = L.call_int('p4p_wgrad_splits', M, N, K)
-    ws = _workspace('wgrad', splits * N * K, g.device)
-    L.call('p4p_gemm_wgrad_bf16', L.ptr(g), L.ptr(a), L.ptr(out), L.ptr(ws), M, N, K, float(beta), _stream())
-    return out
+    ws = _workspace('wgrad', splits * (N * K + N), g.device)
+    if want_bias and bias_out is None:
+        bias_out = torch.empty(N, dtype=torch.float32, device=g.device)
+        assert beta == 0.0
+    L.call('p4p_gemm_wgrad_bf16', L.ptr(g), L.ptr(a), L.ptr(out), L.ptr(bias_out), L.ptr(ws), M, N, K, float(beta),
+           _stream())
+    return (out, bias_out) if want_bias else out
 
 
 # ---------------------------------------------------------------- LayerNorm
@@ -158,8 +163,8 @@ def layernorm_bwd(dy, xin, mean, rstd, gamma, dx=None, dgamma=None, dbeta=None, 
     if dx is None:
         dx = torch.empty(M, D, dtype=torch.float32, device=xin.device)
     if dgamma is None:
-        dgamma = torch.empty(D, dtype=torch.float32, device=xin.device)
-        dbeta = torch.empty(D, dtype=torch.float32, device=xin.device)
+        dgb = torch.empty(2, D, dtype=torch.float32, device=xin.device)     # contiguous: one reduce launch
+        dgamma, dbeta = dgb[0], dgb[1]
         beta_acc = 0.0
     rows = L.call_int('p4p_layernorm_bwd_partial_rows')
     part = _workspace('lnbwd', rows * 2 * D, xin.device)

@@ -55,9 +55,10 @@ int p4p_gemm_tn_bf16(int epilogue, const void* A, const void* W, void* out, cons
 int p4p_gemm_tn_stats_rows(int M);
 
 /* dW[N,K] (f32) = beta*dW + G[M,N]^T A[M,K]  (autograd of nn.Linear.weight).  N,K % 8 == 0.
- * workspace: p4p_wgrad_splits(M,N,K) * N * K floats (deterministic split reduction, no atomics). */
-int p4p_gemm_wgrad_bf16(const void* G, const void* A, float* dW, float* workspace, int M, int N, int K, float beta,
-                        void* stream);
+ * dbias[N] (may be NULL) = beta*dbias + column sums of G (autograd of nn.Linear.bias), from the same pass.
+ * workspace: p4p_wgrad_splits(M,N,K) * (N*K + N) floats (deterministic split reduction, no atomics). */
+int p4p_gemm_wgrad_bf16(const void* G, const void* A, float* dW, float* dbias, float* workspace, int M, int N, int K,
+                        float beta, void* stream);
 int p4p_wgrad_splits(int M, int N, int K);
 
 /* ---- LayerNorm (timm Block.norm1/norm2, VisionTransformer.norm; eps 1e-6) ------------------------- */

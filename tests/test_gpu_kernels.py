@@ -179,6 +179,12 @@ def test_gemm_tn_epilogues_random():
     # tolerance: one bf16 rounding of the output (2^-8 relative) on top of fp32 accumulation
     torch.testing.assert_close(pre.float(), ref, rtol=1e-2, atol=1e-2)
     torch.testing.assert_close(out.float(), torch.nn.functional.gelu(ref), rtol=1e-2, atol=1e-2)
+    # the fast erf (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7) against libm on a dense grid incl. the tails
+    xs = torch.linspace(-9, 9, 128 * 64, device=DEV).view(128, 64)
+    eye = torch.eye(64, device=DEV).to(torch.bfloat16)
+    xb = xs.to(torch.bfloat16)
+    gl = ops.gemm_tn(xb, eye, ops.EPI_BF16_GELU, bias=torch.zeros(64, device=DEV))
+    torch.testing.assert_close(gl.float(), torch.nn.functional.gelu(xb.float()), rtol=8e-3, atol=1e-6)
     dg = ops.gemm_tn(a, w, ops.EPI_BF16_DGELU, pre=pre)
     x = pre.float().requires_grad_(True)
     torch.nn.functional.gelu(x).sum().backward()
@@ -205,6 +211,9 @@ def test_gemm_wgrad_exact_on_integer_data(M, N, K):
     assert torch.equal(got, want)
     acc = ops.gemm_wgrad(g, a, out=got.clone(), beta=1.0)
     assert torch.equal(acc, 2 * want)
+    dw, db = ops.gemm_wgrad(g, a, want_bias=True)          # bias gradient from the same pass
+    assert torch.equal(dw, want) and torch.equal(db, g.float().sum(0))
+    assert torch.equal(ops.colsum(g), g.float().sum(0))
 
 
 # ------------------------------------------------------------------------------------------ LayerNorm
