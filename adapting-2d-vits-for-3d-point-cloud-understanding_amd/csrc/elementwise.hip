@@ -62,13 +62,21 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16* __restri
     }
 }
 
-__global__ void colreduce2_kernel(const float* __restrict__ part, float* __restrict__ out, int nrows, int ncols,
-                                  float beta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncols) return;
+// 256 threads = 32 columns x 8 row lanes (fixed order: reproducible)
+__global__ __launch_bounds__(256) void colreduce2_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                          int nrows, int ncols, float beta) {
+    __shared__ float red[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
     float s = 0.f;
-    for (int r = 0; r < nrows; ++r) s += part[(size_t)r * ncols + c];
-    out[c] = beta != 0.f ? beta * out[c] + s : s;
+    if (c < ncols)
+        for (int r = ty; r < nrows; r += 8) s += part[(size_t)r * ncols + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < ncols) {
+        float v = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) + ((red[4][tx] + red[5][tx]) + (red[6][tx] + red[7][tx]));
+        out[c] = beta != 0.f ? beta * out[c] + v : v;
+    }
 }
 
 // Token stream <-> compact patch rows.  stream row of patch (b,s) = b*T + 1 + s  (T = S + 1).
@@ -139,7 +147,7 @@ extern "C" int p4p_colsum_bf16(const void* G, float* out, float* workspace, int 
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3(ceil_div(N, 256), splits), dim3(256), 0, st, (const __bf16*)G, workspace,
                        M, N, rps);
     P4P_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colreduce2_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, workspace, out, splits, N, beta);
+    hipLaunchKernelGGL(colreduce2_kernel, dim3(ceil_div(N, 32)), dim3(256), 0, st, workspace, out, splits, N, beta);
     P4P_LAUNCH_CHECK();
     return 0;
 }

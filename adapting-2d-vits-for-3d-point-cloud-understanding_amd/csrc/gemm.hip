@@ -20,12 +20,15 @@
 // D lane l reg r -> D[4(l>>4)+r][l&15].  We pass the W (resp. A-matrix) fragment as the MFMA "A"
 // operand so each lane ends up with 4 CONSECUTIVE output columns of one output row: 8-B bf16 /
 // 16-B fp32 stores.
-#include "gemm_tn.h"
-#include "gemm_tn3.h"
-
-#define GEMM_THREADS 256
+#include "common.h"
 
 __device__ float g_zero_page[64];   // 256 B of zeros: LDS-DMA source for rows past the end (wgrad)
+
+#include "gemm_tn.h"
+#include "gemm_tn3.h"
+#include "gemm_wgrad3.h"
+
+#define GEMM_THREADS 256
 
 // tile configuration: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x128 (8 waves), 3 = 256x256 (8 waves),
 // 4 = 256x128 / 4 waves / K-step 32 / 3-stage ring (gemm_tn3.h); 11-13 = 1-3 with pinned scheduling
@@ -56,9 +59,10 @@ static int launch_tn(const GemmParams& p, hipStream_t st) {
         else v = 1;
     }
     if constexpr (!STATS) {
-        if (v == 4 && p.N % T3_BN == 0) {
+        if ((v == 4 || v == 5) && p.N % T3_BN == 0) {
             int tiles = ceil_div(p.M, T3_BM) * (p.N / T3_BN);
-            hipLaunchKernelGGL(gemm_tn3_kernel<EPI>, dim3(tiles), dim3(T3_THREADS), 0, st, p);
+            if (v == 5) hipLaunchKernelGGL((gemm_tn3_kernel<EPI, true>), dim3(tiles), dim3(T3_THREADS), 0, st, p);
+            else hipLaunchKernelGGL((gemm_tn3_kernel<EPI, false>), dim3(tiles), dim3(T3_THREADS), 0, st, p);
             P4P_LAUNCH_CHECK();
             return 0;
         }
@@ -248,7 +252,21 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
     *reinterpret_cast<f32x4*>(out + e) = s;
 }
 
+static bool wgrad_use_v3(int M, int N, int K) { return N % W3_BN == 0 && K % W3_BK == 0 && M >= 4096; }
+static int wgrad3_steps_per_split(int M, int N, int K) {
+    int tiles = (N / W3_BN) * (K / W3_BK);
+    int steps = ceil_div(M, 32);
+    int want = (512 + tiles / 2) / tiles;          // ~2 workgroups per CU over the whole grid
+    if (want < 1) want = 1;
+    if (want > steps) want = steps;
+    return ceil_div(steps, want);
+}
+
+extern "C" int p4p_colsum_bf16(const void* G, float* out, float* workspace, int M, int N, float beta, void* stream);
+
 extern "C" int p4p_wgrad_splits(int M, int N, int K) {
+    // the ring kernel keeps the column-sum partials (<= 256 rows of N floats) behind its slabs: +2 slabs (K >= 128) cover them
+    if (wgrad_use_v3(M, N, K)) return ceil_div(ceil_div(M, 32), wgrad3_steps_per_split(M, N, K)) + 2;
     int tiles = ceil_div(N, 128) * ceil_div(K, 128);
     int chunks = ceil_div(M, WG_BMR);
     int want = ceil_div(1024, tiles);             // ~4 workgroups per CU over the whole grid
@@ -265,6 +283,24 @@ extern "C" int p4p_gemm_wgrad_bf16(const void* G, const void* A, float* dW, floa
     P4P_CHECK(M >= 1 && N >= 8 && K >= 8, "p4p_gemm_wgrad_bf16: bad sizes M=%d N=%d K=%d", M, N, K);
     P4P_CHECK(N % 8 == 0 && K % 8 == 0, "p4p_gemm_wgrad_bf16: N=%d and K=%d must be multiples of 8", N, K);
     hipStream_t st = (hipStream_t)stream;
+    if (wgrad_use_v3(M, N, K)) {
+        P4P_CHECK(workspace, "p4p_gemm_wgrad_bf16: workspace required");
+        W3Params q;
+        q.G = (const __bf16*)G; q.A = (const __bf16*)A; q.M = M; q.N = N; q.K = K;
+        q.steps_per_split = wgrad3_steps_per_split(M, N, K);
+        int splits3 = ceil_div(ceil_div(M, 32), q.steps_per_split);
+        q.out = workspace;
+        hipLaunchKernelGGL(gemm_wgrad3_kernel, dim3((N / W3_BN) * (K / W3_BK), splits3), dim3(256), 0, st, q);
+        P4P_LAUNCH_CHECK();
+        long long n = (long long)N * K;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(n / 4, 256)), dim3(256), 0, st, workspace, dW, n, splits3,
+                           beta);
+        P4P_LAUNCH_CHECK();
+        if (dbias) {       // streaming column sum of G; its partials live behind the slabs
+            return p4p_colsum_bf16(G, dbias, workspace + (size_t)splits3 * N * K, M, N, beta, stream);
+        }
+        return 0;
+    }
     int splits = p4p_wgrad_splits(M, N, K);
     int chunks = ceil_div(M, WG_BMR);
     WgradParams p;

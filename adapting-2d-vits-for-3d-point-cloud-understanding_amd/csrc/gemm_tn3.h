@@ -37,13 +37,21 @@ struct T3Frags {
     bf16x8 w[4];
 };
 
-template <int EPI>
+template <int EPI, bool PAIR>
 __global__ __launch_bounds__(T3_THREADS, 2) void gemm_tn3_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[T3_LDS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = p.N / T3_BN, tiles_m = (p.M + T3_BM - 1) / T3_BM;
-    const int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    if (PAIR) {
+        // within every run of 64 tiles of one XCD: dispatch slot c and c+32 (observed to share a CU: an XCD
+        // has 32 CUs and takes 2 of these workgroups each) get neighbouring tiles 2c, 2c+1 = same A panel
+        const int nwg = tiles_m * tiles_n, per = nwg >> 3;
+        const int xcd_base = tile - ((blockIdx.x >> 3));
+        const int loc = blockIdx.x >> 3;
+        if (((loc | 63) < per)) tile = xcd_base + (loc & ~63) + (((loc & 31) << 1) | ((loc >> 5) & 1));
+    }
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * T3_BM, n0 = tn * T3_BN;
     const int nk = p.K / 32;

@@ -276,3 +276,18 @@ def test_attention_fwd_bwd(B, T, H):
         spike = spike.view(B * T, 3 * D).contiguous()
         out2, _ = ops.attention_fwd(spike, B, T, H)
         torch.testing.assert_close(out2.float(), _attn_ref(spike, B, T, H), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize('M,N,K', [(4096, 256, 128), (5000, 768, 768), (4099, 512, 256), (65792, 768, 256)])
+def test_gemm_wgrad_ring_kernel_exact_on_integer_data(M, N, K):
+    """Shapes that take the 256x128 ring kernel (N%256==0, K%128==0, M>=4096), incl. a ragged M tail."""
+    g = _int_bf16((M, N), -1, 1, 5).to(DEV)
+    a = _int_bf16((M, K), -2, 2, 6).to(DEV)
+    if M > 20000:
+        g = (g * (torch.rand(M, N, device=DEV) < 0.05)).to(torch.bfloat16).contiguous()   # keep sums exact in fp32
+    want = g.float().t() @ a.float()
+    dw, db = ops.gemm_wgrad(g, a, want_bias=True)
+    assert torch.equal(dw, want)
+    assert torch.equal(db, g.float().sum(0))
+    acc = ops.gemm_wgrad(g, a, out=dw.clone(), beta=1.0)
+    assert torch.equal(acc, 2 * want)
