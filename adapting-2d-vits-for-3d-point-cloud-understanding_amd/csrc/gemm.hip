@@ -54,11 +54,40 @@ static int launch_tn(const GemmParams& p, hipStream_t st) {
         //   GELU / fp32 residual / dGELU epilogues: the 2-workgroups-per-CU 256x128 ring overlaps the
         //   HBM / VALU-heavy epilogue with the other workgroup's MFMA loop
         const bool big = (long long)ceil_div(p.M, 256) * ceil_div(p.N, 128) >= 512;
-        if (EPI == EPI_BF16 && p.N % 256 == 0 && (long long)ceil_div(p.M, 256) * (p.N / 256) >= 256) v = 3;
+        const bool big256 = p.N % 256 == 0 && (long long)ceil_div(p.M, 256) * (p.N / 256) >= 256;
+        if (EPI == EPI_BF16_GELU && p.N % T3_BN == 0 && big) v = 4;      // 2 pre/gelu outputs: overlap wins (600 vs 540)
+        else if (big256) v = 3;                                          // 256x256: 790-1070 TFLOP/s vs 690-850
         else if (p.N % T3_BN == 0 && big) v = 4;
         else v = 1;
     }
     if constexpr (!STATS) {
+        // Grid quantisation: with few rounds of big tiles (M = 256*257 and N = 768 give 771 tiles of 256x256 on
+        // 256 CUs = 3 rounds + 3 tiles -> a 4th round for 0.4% of the work, measured -15..20%), peel the last
+        // row tile(s) off and run them with the 128x128 configuration (many small workgroups, one short round).
+        if ((v == 3 || v == 4 || v == 5) && p.M % 256 == 0) {
+            const int bn = v == 3 ? 256 : T3_BN, slots = v == 3 ? 256 : 512;
+            const int tiles_n = ceil_div(p.N, bn), tiles_m = p.M / 256;
+            const long long total = (long long)tiles_m * tiles_n;
+            const long long rounds = total / slots, rem = total % slots;
+            if (rounds >= 1 && rounds <= 4 && rem > 0 && rem * 8 <= slots && rem % tiles_n == 0 && rem / tiles_n < tiles_m) {
+                const int peel = (int)(rem / tiles_n) * 256;            // rows handled by the small-tile launch
+                GemmParams a = p, b = p;
+                a.M = p.M - peel;
+                const size_t ro = (size_t)a.M;
+                b.M = peel;
+                b.A = p.A + ro * p.K;
+                b.out = (char*)p.out + ro * p.N * (EPI == EPI_F32_RESID ? 4 : 2);
+                if (p.resid) b.resid = p.resid + ro * p.N;
+                if (p.pre) b.pre = p.pre + ro * p.N;
+                const int saved = g_gemm_variant;
+                g_gemm_variant = v;                                     // main part: no further peeling (rem == 0)
+                int rc = launch_tn<EPI>(a, st);
+                g_gemm_variant = 6;                                     // 64x64 tiles: 4x more workgroups for the short tail
+                if (!rc) rc = launch_tn<EPI>(b, st);
+                g_gemm_variant = saved;
+                return rc;
+            }
+        }
         if ((v == 4 || v == 5) && p.N % T3_BN == 0) {
             int tiles = ceil_div(p.M, T3_BM) * (p.N / T3_BN);
             if (v == 5) hipLaunchKernelGGL((gemm_tn3_kernel<EPI, true>), dim3(tiles), dim3(T3_THREADS), 0, st, p);
@@ -66,6 +95,7 @@ static int launch_tn(const GemmParams& p, hipStream_t st) {
             P4P_LAUNCH_CHECK();
             return 0;
         }
+        if (v == 6) return launch_cfg<64, 64, 2, 2, EPI>(p, st);
         if (v == 3) return launch_cfg<256, 256, 2, 4, EPI>(p, st);
         if (v == 2) return launch_cfg<256, 128, 4, 2, EPI>(p, st);
         if (v == 13) return launch_cfg<256, 256, 2, 4, EPI, true>(p, st);

@@ -6,7 +6,7 @@ import p4p_amd
 from p4p_amd import ops, _lib
 dev = 'cuda'
 lib = _lib.lib()
-M, D = 256 * 257, 768
+M, D = int(os.environ.get("GB_M", 256 * 257)), 768
 shapes = {'qkv': (M, 3 * D, D, ops.EPI_BF16), 'proj': (M, D, D, ops.EPI_F32_RESID), 'fc1': (M, 4 * D, D, ops.EPI_BF16_GELU),
           'fc2': (M, D, 4 * D, ops.EPI_F32_RESID), 'dfc2': (M, 4 * D, D, ops.EPI_BF16_DGELU), 'dfc1': (M, D, 4 * D, ops.EPI_BF16)}
 variants = [int(v) for v in (sys.argv[1].split(',') if len(sys.argv) > 1 else '1,2,3,11,12,13'.split(','))]
