@@ -70,7 +70,8 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(const float* 
 }
 
 // dx (+)= rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  partial[blk][0][c] = sum dy*xhat,
-// partial[blk][1][c] = sum dy over the rows this block handled.
+// partial[blk][1][c] = sum dy, partial[blk][2][c] = sum of the OUTPUT dx (the bias gradient of the Linear that
+// produced this residual stream: proj.bias / fc2.bias) over the rows this block handled.
 template <int J>
 __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(const void* __restrict__ dy, int dy_f32,
                                                                     const float* __restrict__ xin,
@@ -81,13 +82,13 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(const void* _
                                                                     __bf16* __restrict__ dx_bf16,
                                                                     float* __restrict__ dacc, int dacc_init,
                                                                     float* __restrict__ partial, int M, int D) {
-    __shared__ float red[LN_THREADS / 64][2][256 * J];
+    __shared__ float red[LN_THREADS / 64][3][256 * J];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwaves = gridDim.x * (LN_THREADS / 64);
-    f32x4 ag[J], ab[J], g[J];
+    f32x4 ag[J], ab[J], ao[J], g[J];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        ag[j] = ab[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ag[j] = ab[j] = ao[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int c = j * 256 + lane * 4;
         g[j] = c < D ? *reinterpret_cast<const f32x4*>(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(const void* _
                 f32x4 o = (d[j] * g[j] - m1 - xh[j] * m2) * rs;
                 if (accumulate) o += *reinterpret_cast<const f32x4*>(dx + base + c);
                 *reinterpret_cast<f32x4*>(dx + base + c) = o;
+                ao[j] += o;
                 if (dx_bf16) {
                     bf16x4 w = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
                     *reinterpret_cast<bf16x4*>(dx_bf16 + base + c) = w;
@@ -140,14 +142,16 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(const void* _
         const int c = j * 256 + lane * 4;
         *reinterpret_cast<f32x4*>(&red[wave][0][c]) = ag[j];
         *reinterpret_cast<f32x4*>(&red[wave][1][c]) = ab[j];
+        *reinterpret_cast<f32x4*>(&red[wave][2][c]) = ao[j];
     }
     __syncthreads();
     for (int c = threadIdx.x; c < D; c += LN_THREADS) {
-        float a = 0.f, b = 0.f;
+        float a = 0.f, b = 0.f, o = 0.f;
 #pragma unroll
-        for (int w = 0; w < LN_THREADS / 64; ++w) { a += red[w][0][c]; b += red[w][1][c]; }
-        partial[((size_t)blockIdx.x * 2 + 0) * D + c] = a;
-        partial[((size_t)blockIdx.x * 2 + 1) * D + c] = b;
+        for (int w = 0; w < LN_THREADS / 64; ++w) { a += red[w][0][c]; b += red[w][1][c]; o += red[w][2][c]; }
+        partial[((size_t)blockIdx.x * 3 + 0) * D + c] = a;
+        partial[((size_t)blockIdx.x * 3 + 1) * D + c] = b;
+        partial[((size_t)blockIdx.x * 3 + 2) * D + c] = o;
     }
 }
 
@@ -195,11 +199,12 @@ extern "C" int p4p_layernorm_fwd(const float* x, const float* pos, const float* 
     return 0;
 }
 
-// partial: [LN_BWD_BLOCKS][2][D] floats of workspace; dgamma/dbeta = beta_acc * old + column sums.
+// partial: [LN_BWD_BLOCKS][3][D] floats of workspace; dgamma/dbeta/dxsum = beta_acc * old + column sums
+// (dgamma, dbeta, dxsum contiguous as [3][D] or [2][D] takes one reduce launch).
 extern "C" int p4p_layernorm_bwd(const void* dy, int dy_is_f32, const float* xin, const float* mean,
                                  const float* rstd, const float* gamma, float* dx, int accumulate_dx,
                                  void* dx_bf16, float* dacc, int dacc_init, float* partial, float* dgamma,
-                                 float* dbeta, float beta_acc, int M, int D, void* stream) {
+                                 float* dbeta, float* dxsum, float beta_acc, int M, int D, void* stream) {
     P4P_CHECK(dy && xin && mean && rstd && gamma && dx && partial, "p4p_layernorm_bwd: null pointer");
     P4P_CHECK(M >= 1 && D >= 4 && D % 4 == 0 && D <= 2048, "p4p_layernorm_bwd: bad sizes M=%d D=%d", M, D);
     hipStream_t st = (hipStream_t)stream;
@@ -212,20 +217,18 @@ extern "C" int p4p_layernorm_bwd(const void* dy, int dy_is_f32, const float* xin
     if (J <= 1) LN_BWD(1); else if (J <= 2) LN_BWD(2); else if (J <= 3) LN_BWD(3); else if (J <= 4) LN_BWD(4); else LN_BWD(8);
 #undef LN_BWD
     P4P_LAUNCH_CHECK();
-    if (dgamma && dbeta == dgamma + D) {          // contiguous [2][D] destination: one launch
-        hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(2 * D, 32)), dim3(256), 0, st, partial, dgamma, blocks,
-                           (long long)2 * D, 2 * D, beta_acc);
+    if (dgamma && dbeta == dgamma + D && (!dxsum || dxsum == dgamma + 2 * D)) {   // contiguous destination: one launch
+        const int rows = dxsum ? 3 : 2;
+        hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(rows * D, 32)), dim3(256), 0, st, partial, dgamma, blocks,
+                           (long long)3 * D, rows * D, beta_acc);
         P4P_LAUNCH_CHECK();
         return 0;
     }
-    if (dgamma) {
-        hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(D, 32)), dim3(256), 0, st, partial, dgamma, blocks,
-                           (long long)2 * D, D, beta_acc);
-        P4P_LAUNCH_CHECK();
-    }
-    if (dbeta) {
-        hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(D, 32)), dim3(256), 0, st, partial + D, dbeta, blocks,
-                           (long long)2 * D, D, beta_acc);
+    float* dst[3] = {dgamma, dbeta, dxsum};
+    for (int i = 0; i < 3; ++i) {
+        if (!dst[i]) continue;
+        hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(D, 32)), dim3(256), 0, st, partial + (size_t)i * D, dst[i],
+                           blocks, (long long)3 * D, D, beta_acc);
         P4P_LAUNCH_CHECK();
     }
     return 0;

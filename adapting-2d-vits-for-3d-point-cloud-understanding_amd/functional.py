@@ -201,7 +201,10 @@ class _EncoderFn(torch.autograd.Function):
         need = ctx.needs_input_grad           # feats, pos, heads, eps, sink, train, norm_w, norm_b, *bp
         dev = dy.device
         dxb = torch.empty(M, D, dtype=torch.bfloat16, device=dev)
-        dx, dnw, dnb = ops.layernorm_bwd(dy.reshape(M, D).contiguous(), xN, meanN, rstdN, norm_w.detach(), dx_bf16=dxb)
+        # every LayerNorm backward also returns the column sums of the dx it writes: that is the bias gradient of
+        # the Linear whose output gradient dx is (fc2.bias of the block below / proj.bias), with no extra pass
+        dx, dnw, dnb, dx_colsum = ops.layernorm_bwd(dy.reshape(M, D).contiguous(), xN, meanN, rstdN, norm_w.detach(),
+                                                    dx_bf16=dxb, want_dxsum=True)
         dpos = torch.empty(M, D, dtype=torch.float32, device=dev)
         grads = [None] * (L * _BLOCK_PARAMS)
         sink = ctx.grad_sink
@@ -215,23 +218,24 @@ class _EncoderFn(torch.autograd.Function):
             _, Wfc1T = _bf16_weights(fc1w, True)
             dln2 = ops.gemm_tn(dh, Wfc1T, ops.EPI_BF16)
             if wg:
-                dfc2w, dfc2b = ops.gemm_wgrad(dxb, g, want_bias=True)
+                dfc2w, dfc2b = ops.gemm_wgrad(dxb, g), dx_colsum
                 dfc1w, dfc1b = ops.gemm_wgrad(dh, ln2, want_bias=True)
             del dh
-            _, dn2w, dn2b = ops.layernorm_bwd(dln2, x1, mean2, rstd2, n2w.detach(), dx=dx, dx_bf16=dxb)
+            _, dn2w, dn2b, dx_colsum = ops.layernorm_bwd(dln2, x1, mean2, rstd2, n2w.detach(), dx=dx, dx_bf16=dxb,
+                                                         want_dxsum=True)
             # ---- attention: x1 = xin + proj(attn(qkv(ln1)))
             _, WprojT = _bf16_weights(projw, True)
             datt = ops.gemm_tn(dxb, WprojT, ops.EPI_BF16)
             if wg:
-                dprojw, dprojb = ops.gemm_wgrad(dxb, att, want_bias=True)
+                dprojw, dprojb = ops.gemm_wgrad(dxb, att), dx_colsum
             dqkv = ops.attention_bwd(qkv, att, datt, lse, B, T, H)
             _, WqkvT = _bf16_weights(qkvw, True)
             dln1 = ops.gemm_tn(dqkv, WqkvT, ops.EPI_BF16)
             if wg:
                 dqkvw, dqkvb = ops.gemm_wgrad(dqkv, ln1, want_bias=True)
             del dqkv, datt
-            _, dn1w, dn1b = ops.layernorm_bwd(dln1, xin, mean1, rstd1, n1w.detach(), dx=dx, dx_bf16=dxb, dacc=dpos,
-                                              dacc_init=(l == L - 1))
+            _, dn1w, dn1b, dx_colsum = ops.layernorm_bwd(dln1, xin, mean1, rstd1, n1w.detach(), dx=dx, dx_bf16=dxb,
+                                                         dacc=dpos, dacc_init=(l == L - 1), want_dxsum=True)
             if wg:
                 grads[l * _BLOCK_PARAMS:(l + 1) * _BLOCK_PARAMS] = [dn1w, dn1b, dqkvw, dqkvb, dprojw, dprojb, dn2w, dn2b,
                                                                     dfc1w, dfc1b, dfc2w, dfc2b]

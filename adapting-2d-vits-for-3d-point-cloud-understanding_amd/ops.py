@@ -152,7 +152,7 @@ def layernorm_fwd(x, gamma, beta, eps=1e-6, pos=None, want_sum=False, out_f32=Fa
 
 
 def layernorm_bwd(dy, xin, mean, rstd, gamma, dx=None, dgamma=None, dbeta=None, beta_acc=0.0, dx_bf16=None,
-                  dacc=None, dacc_init=False):
+                  dacc=None, dacc_init=False, want_dxsum=False):
     """Returns (dx, dgamma, dbeta); if dx is given the LN gradient is ADDED to it in place.  dx_bf16 gets a
     bf16 copy of the result, dacc accumulates it (positional-embedding gradient)."""
     M, D = xin.shape
@@ -162,15 +162,18 @@ def layernorm_bwd(dy, xin, mean, rstd, gamma, dx=None, dgamma=None, dbeta=None, 
     acc = dx is not None
     if dx is None:
         dx = torch.empty(M, D, dtype=torch.float32, device=xin.device)
+    dxsum = None
     if dgamma is None:
-        dgb = torch.empty(2, D, dtype=torch.float32, device=xin.device)     # contiguous: one reduce launch
-        dgamma, dbeta = dgb[0], dgb[1]
+        dgb = torch.empty(3, D, dtype=torch.float32, device=xin.device)     # contiguous: one reduce launch
+        dgamma, dbeta, dxsum = dgb[0], dgb[1], dgb[2]
         beta_acc = 0.0
     rows = L.call_int('p4p_layernorm_bwd_partial_rows')
-    part = _workspace('lnbwd', rows * 2 * D, xin.device)
+    part = _workspace('lnbwd', rows * 3 * D, xin.device)
     L.call('p4p_layernorm_bwd', L.ptr(dy), int(dy.dtype == torch.float32), L.ptr(xin), L.ptr(mean), L.ptr(rstd),
            L.ptr(gamma), L.ptr(dx), int(acc), L.ptr(dx_bf16), L.ptr(dacc), int(dacc_init), L.ptr(part), L.ptr(dgamma),
-           L.ptr(dbeta), float(beta_acc), M, D, _stream())
+           L.ptr(dbeta), L.ptr(dxsum), float(beta_acc), M, D, _stream())
+    if want_dxsum:
+        return dx, dgamma, dbeta, dxsum
     return dx, dgamma, dbeta
 
 

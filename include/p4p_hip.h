@@ -67,13 +67,16 @@ int p4p_wgrad_splits(int M, int N, int K);
  * (the `feats + pos_embed` of src/models/pix4point.py:255); y bf16 or f32; mean/rstd [M] (may be NULL). */
 int p4p_layernorm_fwd(const float* x, const float* pos, const float* gamma, const float* beta, float eps,
                       float* xsum, void* y, int y_is_f32, float* mean, float* rstd, int M, int D, void* stream);
-/* dx = (accumulate_dx ? dx : 0) + LN'(dy); dgamma/dbeta = beta_acc*old + sums (either may be NULL).
+/* dx = (accumulate_dx ? dx : 0) + LN'(dy); dgamma/dbeta = beta_acc*old + sums (either may be NULL);
+ * dxsum (may be NULL) = beta_acc*old + column sums of the resulting dx: the bias gradient of the Linear that wrote
+ * this residual stream (proj.bias / fc2.bias), free of an extra pass.
  * dx_bf16 (may be NULL) receives a bf16 copy of dx (next GEMM operand); dacc (may be NULL) accumulates dx
  * (gradient of the positional embedding that is re-added before every block, pix4point.py:255).
- * partial: [p4p_layernorm_bwd_partial_rows()][2][D] f32 workspace. */
+ * partial: [p4p_layernorm_bwd_partial_rows()][3][D] f32 workspace. */
 int p4p_layernorm_bwd(const void* dy, int dy_is_f32, const float* xin, const float* mean, const float* rstd,
                       const float* gamma, float* dx, int accumulate_dx, void* dx_bf16, float* dacc, int dacc_init,
-                      float* partial, float* dgamma, float* dbeta, float beta_acc, int M, int D, void* stream);
+                      float* partial, float* dgamma, float* dbeta, float* dxsum, float beta_acc, int M, int D,
+                      void* stream);
 int p4p_layernorm_bwd_partial_rows(void);
 int p4p_colreduce_f32(const float* part, float* out, int nrows, long long stride, int ncols, float beta, void* stream);
 

@@ -236,8 +236,9 @@ def test_layernorm_fwd_bwd(M, D):
     br = torch.nn.Parameter(beta.clone())
     torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6).backward(dy)
     base = torch.randn(M, D, generator=g).to(DEV)
-    dx, dg, db = ops.layernorm_bwd(dy, xs, mean, rstd, gamma, dx=base.clone())
+    dx, dg, db, dsum = ops.layernorm_bwd(dy, xs, mean, rstd, gamma, dx=base.clone(), want_dxsum=True)
     torch.testing.assert_close(dx, base + xr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dsum, dx.sum(0), rtol=1e-4, atol=1e-3)     # bias gradient by-product
     torch.testing.assert_close(dg, gr.grad, rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(db, br.grad, rtol=1e-4, atol=1e-3)
     dx2, _, _ = ops.layernorm_bwd(dy.to(torch.bfloat16), xs, mean, rstd, gamma)
