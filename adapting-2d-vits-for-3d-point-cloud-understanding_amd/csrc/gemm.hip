@@ -55,8 +55,10 @@ static int launch_tn(const GemmParams& p, hipStream_t st) {
         //   HBM / VALU-heavy epilogue with the other workgroup's MFMA loop
         const bool big = (long long)ceil_div(p.M, 256) * ceil_div(p.N, 128) >= 512;
         const bool big256 = p.N % 256 == 0 && (long long)ceil_div(p.M, 256) * (p.N / 256) >= 256;
-        if (EPI == EPI_BF16_GELU && p.N % T3_BN == 0 && big) v = 4;      // 2 pre/gelu outputs: overlap wins (600 vs 540)
-        else if (big256) v = 3;                                          // 256x256: 790-1070 TFLOP/s vs 690-850
+        // 256x256 tile everywhere it fits; the K-step-32 ring + LDS-staged fp32 / double-output epilogue (7) wins for
+        // the residual and GELU epilogues (proj 429 vs 381, fc1 606 vs 538, fc2 801 vs 778 TFLOP/s), the
+        // mid-tile-barrier schedule (3) for plain bf16 / dGELU outputs (qkv 933 vs 868, dfc1 1065 vs 997)
+        if (big256) v = (EPI == EPI_F32_RESID || EPI == EPI_BF16_GELU) ? 7 : 3;
         else if (p.N % T3_BN == 0 && big) v = 4;
         else v = 1;
     }
@@ -64,8 +66,8 @@ static int launch_tn(const GemmParams& p, hipStream_t st) {
         // Grid quantisation: with few rounds of big tiles (M = 256*257 and N = 768 give 771 tiles of 256x256 on
         // 256 CUs = 3 rounds + 3 tiles -> a 4th round for 0.4% of the work, measured -15..20%), peel the last
         // row tile(s) off and run them with the 128x128 configuration (many small workgroups, one short round).
-        if ((v == 3 || v == 4 || v == 5) && p.M % 256 == 0) {
-            const int bn = v == 3 ? 256 : T3_BN, slots = v == 3 ? 256 : 512;
+        if ((v == 3 || v == 4 || v == 5 || v == 7) && p.M % 256 == 0) {
+            const int bn = (v == 3 || v == 7) ? 256 : T3_BN, slots = (v == 3 || v == 7) ? 256 : 512;
             const int tiles_n = ceil_div(p.N, bn), tiles_m = p.M / 256;
             const long long total = (long long)tiles_m * tiles_n;
             const long long rounds = total / slots, rem = total % slots;
@@ -90,8 +92,14 @@ static int launch_tn(const GemmParams& p, hipStream_t st) {
         }
         if ((v == 4 || v == 5) && p.N % T3_BN == 0) {
             int tiles = ceil_div(p.M, T3_BM) * (p.N / T3_BN);
-            if (v == 5) hipLaunchKernelGGL((gemm_tn3_kernel<EPI, true>), dim3(tiles), dim3(T3_THREADS), 0, st, p);
-            else hipLaunchKernelGGL((gemm_tn3_kernel<EPI, false>), dim3(tiles), dim3(T3_THREADS), 0, st, p);
+            if (v == 5) hipLaunchKernelGGL((gemm_tn3_kernel<EPI, true, 128>), dim3(tiles), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_tn3_kernel<EPI, false, 128>), dim3(tiles), dim3(256), 0, st, p);
+            P4P_LAUNCH_CHECK();
+            return 0;
+        }
+        if (v == 7 && p.N % 256 == 0) {          // 256 x 256, 8 waves, K-step 32 ring (1 workgroup per CU)
+            int tiles = ceil_div(p.M, T3_BM) * (p.N / 256);
+            hipLaunchKernelGGL((gemm_tn3_kernel<EPI, false, 256>), dim3(tiles), dim3(512), 0, st, p);
             P4P_LAUNCH_CHECK();
             return 0;
         }

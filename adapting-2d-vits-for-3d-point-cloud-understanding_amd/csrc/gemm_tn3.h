@@ -22,11 +22,8 @@
 #include "gemm_tn.h"
 
 #define T3_BM 256
-#define T3_BN 128
+#define T3_BN 128                                // narrow variant (2 workgroups per CU); the wide one is 256
 #define T3_THREADS 256
-#define T3_STAGE ((T3_BM + T3_BN) * 64)          // 24 KiB
-#define T3_PPW (((T3_BM + T3_BN) / 16) / 4)      // 1-KiB pieces per wave per stage = 6
-#define T3_LDS (3 * T3_STAGE)                    // 72 KiB
 // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0]|[15:14], expcnt[6:4], lgkmcnt[11:8]); the BUILTIN keeps
 // hipcc's own wait-count bookkeeping in sync (it cannot see through inline asm)
 #define WAIT_VM(n) __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
@@ -37,12 +34,19 @@ struct T3Frags {
     bf16x8 w[4];
 };
 
-template <int EPI, bool PAIR>
-__global__ __launch_bounds__(T3_THREADS, 2) void gemm_tn3_kernel(GemmParams p) {
+template <int EPI, bool PAIR, int BN_>
+__global__ __launch_bounds__(BN_ * 2, 2) void gemm_tn3_kernel(GemmParams p) {
+    constexpr int NWN = BN_ / 64, NW = 2 * NWN, NTHR = NW * 64;      // waves: 2 (M) x NWN (N), each 128 x 64
+    constexpr int T3_STAGE = (T3_BM + BN_) * 64;                      // 24 / 32 KiB per K-step of 32
+    constexpr int T3_PPW = ((T3_BM + BN_) / 16) / NW;                 // 1-KiB LDS-DMA pieces per wave: 6 / 4
+    constexpr int CS16 = BN_ * 2 + 16;                                // bf16 staging row stride
+    constexpr int CS32 = BN_ * 4 + 16;                                // fp32 staging row stride
+    constexpr int T3_LDS = (3 * T3_STAGE) > (T3_BM * CS16) ? (3 * T3_STAGE) : (T3_BM * CS16);
+    static_assert(128 * CS32 <= T3_LDS, "fp32 epilogue pass must fit");
     __shared__ __attribute__((aligned(1024))) char lds[T3_LDS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = p.N / T3_BN, tiles_m = (p.M + T3_BM - 1) / T3_BM;
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int tiles_n = p.N / BN_, tiles_m = (p.M + T3_BM - 1) / T3_BM;
     int tile = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     if (PAIR) {
         // within every run of 64 tiles of one XCD: dispatch slot c and c+32 (observed to share a CU: an XCD
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(T3_THREADS, 2) void gemm_tn3_kernel(GemmParams p) {
         if (((loc | 63) < per)) tile = xcd_base + (loc & ~63) + (((loc & 31) << 1) | ((loc >> 5) & 1));
     }
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const int m0 = tm * T3_BM, n0 = tn * T3_BN;
+    const int m0 = tm * T3_BM, n0 = tn * BN_;
     const int nk = p.K / 32;
 
     // ---- staging: piece = 16 rows x 64 B; pieces [0,16) are A rows, [16,24) are W rows
@@ -167,8 +171,6 @@ __global__ __launch_bounds__(T3_THREADS, 2) void gemm_tn3_kernel(GemmParams p) {
     // lane holds, for (i,j): row ml = wm*128 + j*16 + li, cols nl = wn*64 + i*16 + 4g .. +3
     // =============================================================================================
     __syncthreads();
-    constexpr int CS16 = T3_BN * 2 + 16;              // bf16 staging row stride (272 B)
-    constexpr int CS32 = T3_BN * 4 + 16;              // fp32 staging row stride (528 B)
     f32x4 bias4[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -188,8 +190,8 @@ __global__ __launch_bounds__(T3_THREADS, 2) void gemm_tn3_kernel(GemmParams p) {
                             acc[i][j] + bias4[i];
             }
             __syncthreads();
-            for (int c = t; c < 128 * 32; c += T3_THREADS) {
-                const int rl = c >> 5, cc = c & 31;
+            for (int c = t; c < 128 * (BN_ / 4); c += NTHR) {
+                const int rl = c / (BN_ / 4), cc = c % (BN_ / 4);
                 const int m = m0 + pass * 128 + rl;
                 if (m < p.M) {
                     const size_t o = (size_t)m * p.N + n0 + cc * 4;
@@ -205,8 +207,8 @@ __global__ __launch_bounds__(T3_THREADS, 2) void gemm_tn3_kernel(GemmParams p) {
 
     // bf16 outputs: copy the whole 256 x 128 tile between LDS and global with 16-B chunks (16 per row)
     auto copy_out = [&](__bf16* dst) {
-        for (int c = t; c < T3_BM * 16; c += T3_THREADS) {
-            const int rl = c >> 4, cc = c & 15;
+        for (int c = t; c < T3_BM * (BN_ / 8); c += NTHR) {
+            const int rl = c / (BN_ / 8), cc = c % (BN_ / 8);
             const int m = m0 + rl;
             if (m < p.M)
                 *reinterpret_cast<u32x4*>(dst + (size_t)m * p.N + n0 + cc * 8) =
@@ -214,8 +216,8 @@ __global__ __launch_bounds__(T3_THREADS, 2) void gemm_tn3_kernel(GemmParams p) {
         }
     };
     if (EPI == EPI_BF16_DGELU) {
-        for (int c = t; c < T3_BM * 16; c += T3_THREADS) {         // pre-activation tile -> LDS, coalesced
-            const int rl = c >> 4, cc = c & 15;
+        for (int c = t; c < T3_BM * (BN_ / 8); c += NTHR) {        // pre-activation tile -> LDS, coalesced
+            const int rl = c / (BN_ / 8), cc = c % (BN_ / 8);
             int m = m0 + rl;
             m = m < p.M ? m : p.M - 1;
             *reinterpret_cast<u32x4*>(lds + rl * CS16 + cc * 16) =
