@@ -291,10 +291,14 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
 }
 
 static bool wgrad_use_v3(int M, int N, int K) { return N % W3_BN == 0 && K % W3_BK == 0 && M >= 4096; }
+static int g_wgrad_wide = 1;
+extern "C" int p4p_set_wgrad_wide(int v) { int o = g_wgrad_wide; g_wgrad_wide = v; return o; }
+static bool wgrad3_wide(int K) { return g_wgrad_wide && K % 256 == 0; }      // 256x256 tile, 8 waves, 1 workgroup per CU
 static int wgrad3_steps_per_split(int M, int N, int K) {
-    int tiles = (N / W3_BN) * (K / W3_BK);
+    const int bk = wgrad3_wide(K) ? 256 : W3_BK, slots = wgrad3_wide(K) ? 256 : 512;
+    int tiles = (N / W3_BN) * (K / bk);
     int steps = ceil_div(M, 32);
-    int want = (512 + tiles / 2) / tiles;          // ~2 workgroups per CU over the whole grid
+    int want = slots / tiles;                      // one round: never more workgroups than resident slots
     if (want < 1) want = 1;
     if (want > steps) want = steps;
     return ceil_div(steps, want);
@@ -328,7 +332,10 @@ extern "C" int p4p_gemm_wgrad_bf16(const void* G, const void* A, float* dW, floa
         q.steps_per_split = wgrad3_steps_per_split(M, N, K);
         int splits3 = ceil_div(ceil_div(M, 32), q.steps_per_split);
         q.out = workspace;
-        hipLaunchKernelGGL(gemm_wgrad3_kernel, dim3((N / W3_BN) * (K / W3_BK), splits3), dim3(256), 0, st, q);
+        if (wgrad3_wide(K))
+            hipLaunchKernelGGL(gemm_wgrad3_kernel<256>, dim3((N / W3_BN) * (K / 256), splits3), dim3(512), 0, st, q);
+        else
+            hipLaunchKernelGGL(gemm_wgrad3_kernel<128>, dim3((N / W3_BN) * (K / W3_BK), splits3), dim3(256), 0, st, q);
         P4P_LAUNCH_CHECK();
         long long n = (long long)N * K;
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(n / 4, 256)), dim3(256), 0, st, workspace, dW, n, splits3,

@@ -11,9 +11,7 @@
 #include "gemm_tn3.h"
 
 #define W3_BN 256      // n columns of G per tile
-#define W3_BK 128      // k columns of A per tile
-#define W3_STAGE (32 * (W3_BN + W3_BK) * 2)      // 24 KiB
-#define W3_PPW 6
+#define W3_BK 128      // k columns of A per tile (narrow variant, 4 waves, 2 workgroups per CU); wide: 256, 8 waves
 
 struct W3Params {
     const __bf16* G;   // [M,N]
@@ -39,21 +37,29 @@ __device__ __forceinline__ bf16x8 w3_tr(int lo, int hi) {
     return __builtin_bit_cast(bf16x8, r);
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_wgrad3_kernel(W3Params p) {
+template <int BK_>
+__global__ __launch_bounds__(BK_ * 2, 2) void gemm_wgrad3_kernel(W3Params p) {
+    constexpr int NWK = BK_ / 64, NW = 2 * NWK;                       // waves: 2 (n) x NWK (k), each 128 x 64
+    constexpr int W3_STAGE = 32 * (W3_BN + BK_) * 2;                   // 24 / 32 KiB per 32-row step
+    constexpr int APIECES = BK_ / 32;                                  // 1-KiB pieces of the A tile: 4 / 8 ... per 32 rows
+    constexpr int ROWS_PER_APIECE = 1024 / (BK_ * 2);                  // 4 / 2
+    constexpr int W3_PPW = (16 + 32 / ROWS_PER_APIECE) / NW;           // pieces per wave: 6 / 4
+    constexpr int GPW = 16 / NW;                                       // G pieces per wave: 4 / 2
     __shared__ __attribute__((aligned(1024))) char lds[3 * W3_STAGE];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wn = wave >> 1, wk = wave & 1;
-    const int tiles_k = p.K / W3_BK;
+    const int wn = wave / NWK, wk = wave % NWK;
+    const int tiles_k = p.K / BK_;
     const int tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
-    const int n0 = tn * W3_BN, k0 = tk * W3_BK;
+    const int n0 = tn * W3_BN, k0 = tk * BK_;
+    (void)APIECES;
     const int split = blockIdx.y;
     const int total_steps = (p.M + 31) / 32;
     const int step0 = split * p.steps_per_split;
     int nk = total_steps - step0;
     nk = nk < p.steps_per_split ? nk : p.steps_per_split;          // >= 1 by construction of the grid
 
-    // ---- staging.  LDS pieces [0,16): G, 2 rows of 512 B each; [16,24): A, 4 rows of 256 B each.  Every wave
-    // moves 4 G pieces (4*wave + q) and 2 A pieces (16 + 2*wave + q-4): the G/A split is compile-time per q.
+    // ---- staging.  LDS pieces [0,16): G, 2 rows of 512 B each; then A pieces of 1 KiB (4 rows of 256 B, or 2 rows
+    // of 512 B in the wide variant).  Every wave moves GPW G pieces and W3_PPW-GPW A pieces: compile-time per q.
     // Only the last 32-row step of the matrix can be ragged, and the branch-free steady-state loop never
     // stages it, so only the prologue / tail path checks rows against M (zero page beyond the end).
     const __bf16* zero = reinterpret_cast<const __bf16*>(g_zero_page);
@@ -62,29 +68,33 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad3_kernel(W3Params p) {
     const char* abase = reinterpret_cast<const char*>(p.A) + (size_t)step0 * 32 * p.K * 2;
 #pragma unroll
     for (int q = 0; q < W3_PPW; ++q) {
-        if (q < 4) {
-            const int r = (wave * 4 + q) * 2 + (lane >> 5);
+        if (q < GPW) {
+            const int r = (wave * GPW + q) * 2 + (lane >> 5);
             const int h = (r & 3) | (((r >> 3) & 1) << 2);
             soff[q] = ((u32)r * p.N + n0 + (((lane & 31) ^ (h << 1)) * 8)) * 2u;
         } else {
-            const int r = (wave * 2 + q - 4) * 4 + (lane >> 4);
+            constexpr int LPR = 64 / ROWS_PER_APIECE;                  // lanes per A row: 16 / 32
+            const int r = (wave * (W3_PPW - GPW) + q - GPW) * ROWS_PER_APIECE + lane / LPR;
             const int h = (r & 3) | (((r >> 3) & 1) << 2);
-            soff[q] = ((u32)r * p.K + k0 + (((lane & 15) ^ (h << 1)) * 8)) * 2u;
+            soff[q] = ((u32)r * p.K + k0 + (((lane % LPR) ^ (h << 1)) * 8)) * 2u;
         }
     }
-    auto lds_piece = [&](int q) { return q < 4 ? (wave * 4 + q) * 1024 : (16 + wave * 2 + q - 4) * 1024; };
+    auto lds_piece = [&](int q) {
+        return q < GPW ? (wave * GPW + q) * 1024 : (16 + wave * (W3_PPW - GPW) + q - GPW) * 1024;
+    };
     auto stage_fast = [&](int kt, char* buf) {
 #pragma unroll
         for (int q = 0; q < W3_PPW; ++q)
-            __builtin_amdgcn_global_load_lds(GLB_PTR((q < 4 ? gbase : abase) + (size_t)kt * 64 * (q < 4 ? p.N : p.K) + soff[q]),
+            __builtin_amdgcn_global_load_lds(GLB_PTR((q < GPW ? gbase : abase) + (size_t)kt * 64 * (q < GPW ? p.N : p.K) + soff[q]),
                                              LDS_PTR(buf + lds_piece(q)), 16, 0, 0);
     };
     auto stage = [&](int kt, char* buf) {
         const int mbase = (step0 + kt) * 32;
 #pragma unroll
         for (int q = 0; q < W3_PPW; ++q) {
-            const int r = q < 4 ? (wave * 4 + q) * 2 + (lane >> 5) : (wave * 2 + q - 4) * 4 + (lane >> 4);
-            const __bf16* g = reinterpret_cast<const __bf16*>((q < 4 ? gbase : abase) + (size_t)kt * 64 * (q < 4 ? p.N : p.K) + soff[q]);
+            const int r = q < GPW ? (wave * GPW + q) * 2 + (lane >> 5)
+                                  : (wave * (W3_PPW - GPW) + q - GPW) * ROWS_PER_APIECE + lane / (64 / ROWS_PER_APIECE);
+            const __bf16* g = reinterpret_cast<const __bf16*>((q < GPW ? gbase : abase) + (size_t)kt * 64 * (q < GPW ? p.N : p.K) + soff[q]);
             g = mbase + r < p.M ? g : zero;
             __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(buf + lds_piece(q)), 16, 0, 0);
         }
@@ -107,8 +117,8 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad3_kernel(W3Params p) {
     // cb8 leave them clear), so the XOR swizzle costs one v_xor per read instead of one live VGPR per read
     const int g_lo = r_lo * 512 + wn * 256 + cb8 + (h_lo << 5);
     const int g_hi = r_hi * 512 + wn * 256 + cb8 + (h_hi << 5);
-    const int a_lo = 16384 + r_lo * 256 + cb8 + ((h_lo ^ (wk * 4)) << 5);
-    const int a_hi = 16384 + r_hi * 256 + cb8 + ((h_hi ^ (wk * 4)) << 5);
+    const int a_lo = 16384 + r_lo * (BK_ * 2) + (wk >> 1) * 256 + cb8 + ((h_lo ^ ((wk & 1) * 4)) << 5);
+    const int a_hi = 16384 + r_hi * (BK_ * 2) + (wk >> 1) * 256 + cb8 + ((h_hi ^ ((wk & 1) * 4)) << 5);
     auto read_frags = [&](int buf_off, W3Frags& f) {
         int bgl = lds_base + buf_off + g_lo, bgh = lds_base + buf_off + g_hi;
         int bal = lds_base + buf_off + a_lo, bah = lds_base + buf_off + a_hi;
