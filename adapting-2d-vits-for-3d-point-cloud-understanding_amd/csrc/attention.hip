@@ -135,16 +135,19 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
             for (int ks = 0; ks < 2; ++ks)
                 s[k16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(kt_lds, k16, ks, lane), qf[ks], s[k16], 0, 0, 0);
         }
-        float mx = -INFINITY;
+        if (kt == nkt - 1 && (T & 63) != 0) {              // wave-uniform: only the ragged last tile masks keys
+#pragma unroll
+            for (int k16 = 0; k16 < 4; ++k16)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kt * 64 + k16 * 16 + 4 * g + r >= T) s[k16][r] = -INFINITY;
+        }
+        float mx = -INFINITY;                               // max of the RAW scores (c > 0 keeps the arg-max)
 #pragma unroll
         for (int k16 = 0; k16 < 4; ++k16)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 64 + k16 * 16 + 4 * g + r;
-                s[k16][r] = key < T ? s[k16][r] * c : -INFINITY;
-                mx = fmaxf(mx, s[k16][r]);
-            }
-        mx = xor_lanes_max(mx);
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[k16][r]);
+        mx = xor_lanes_max(mx) * c;
         const float mnew = fmaxf(m, mx);
         const float alpha = __builtin_amdgcn_exp2f(m - mnew);
         m = mnew;
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
         for (int k16 = 0; k16 < 4; ++k16)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s[k16][r] = __builtin_amdgcn_exp2f(s[k16][r] - mnew);
+                s[k16][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[k16][r], c, -mnew));   // p = 2^(c s - m)
                 ps += s[k16][r];
             }
         lsum = lsum * alpha + ps;
@@ -253,13 +256,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
                 dp[k16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(vt_lds, k16, ks, lane), dof[ks], dp[k16], 0, 0, 0);
             }
         }
+        const bool ragged = kt == nkt - 1 && (T & 63) != 0;
 #pragma unroll
         for (int k16 = 0; k16 < 4; ++k16)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = kt * 64 + k16 * 16 + 4 * g + r;
-                const float pr = key < T ? __builtin_amdgcn_exp2f(s[k16][r] * c - lse) : 0.f;
-                s[k16][r] = pr * (dp[k16][r] - dl) * p.scale;
+                float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[k16][r], c, -lse));
+                if (ragged && kt * 64 + k16 * 16 + 4 * g + r >= T) pr = 0.f;
+                s[k16][r] = pr * ((dp[k16][r] - dl) * p.scale);
             }
         bf16x8 db[2] = {pack_pair(s[0], s[1]), pack_pair(s[2], s[3])};
 #pragma unroll
@@ -346,16 +350,17 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv_kernel(AttnParam
             }
         }
         f32x4 pr[4];
+        const bool ragged_q = qt == nqt - 1 && (T & 63) != 0;
 #pragma unroll
         for (int q16 = 0; q16 < 4; ++q16) {
             const f32x4 lse4 = *reinterpret_cast<const f32x4*>(st + q16 * 16 + 4 * g);
             const f32x4 del4 = *reinterpret_cast<const f32x4*>(st + 64 + q16 * 16 + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int qq = qt * 64 + q16 * 16 + 4 * g + r;
-                const float pv = qq < T ? __builtin_amdgcn_exp2f(s[q16][r] * c - lse4[r]) : 0.f;
+                float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[q16][r], c, -lse4[r]));
+                if (ragged_q && qt * 64 + q16 * 16 + 4 * g + r >= T) pv = 0.f;
                 pr[q16][r] = pv;
-                s[q16][r] = pv * (dp[q16][r] - del4[r]) * p.scale;
+                s[q16][r] = pv * ((dp[q16][r] - del4[r]) * p.scale);
             }
         }
         bf16x8 pb[2] = {pack_pair(pr[0], pr[1]), pack_pair(pr[2], pr[3])};
