@@ -13,3 +13,51 @@ void p4p_set_error(const char* fmt, ...) {
 
 extern "C" const char* p4p_last_error(void) { return g_err; }
 extern "C" int p4p_abi_version(void) { return 1; }
+
+// ---- optional launch profiler: HIP events around exactly one kernel launch (bench.py's roofline) --------
+// kind 1 = weight-gradient GEMM main kernel, kind 2 = gemm_tn main kernel.  Events sit on the launch stream.
+#include <vector>
+struct ProfRec { hipEvent_t a, b; double flops; };
+static int g_prof_kind = 0;
+static std::vector<ProfRec> g_prof;
+static size_t g_prof_used = 0;
+
+extern "C" int p4p_prof_enable(int kind) {
+    g_prof_kind = kind;
+    g_prof_used = 0;
+    return 0;
+}
+
+bool p4p_prof_begin(int kind, double flops, hipStream_t st) {
+    if (kind != g_prof_kind) return false;
+    if (g_prof_used == g_prof.size()) {
+        if (g_prof.size() >= 8192) return false;
+        ProfRec r;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return false;
+        g_prof.push_back(r);
+    }
+    g_prof[g_prof_used].flops = flops;
+    hipEventRecord(g_prof[g_prof_used].a, st);
+    return true;
+}
+
+void p4p_prof_end(hipStream_t st) {
+    hipEventRecord(g_prof[g_prof_used].b, st);
+    ++g_prof_used;
+}
+
+// Synchronises on the recorded events; out[0] = total ms, out[1] = launches, out[2] = total FLOPs.
+extern "C" int p4p_prof_collect(double* out) {
+    double ms = 0.0, fl = 0.0;
+    for (size_t i = 0; i < g_prof_used; ++i) {
+        float t = 0.f;
+        P4P_HIP(hipEventSynchronize(g_prof[i].b));
+        P4P_HIP(hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b));
+        ms += t;
+        fl += g_prof[i].flops;
+    }
+    out[0] = ms; out[1] = (double)g_prof_used; out[2] = fl;
+    g_prof_kind = 0;
+    g_prof_used = 0;
+    return 0;
+}

@@ -124,3 +124,7 @@ __device__ __forceinline__ float sqdist3(float x, float y, float z, float cx, fl
 }
 
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// launch profiler (capi.cpp): brackets one kernel launch with HIP events when enabled for `kind`
+bool p4p_prof_begin(int kind, double flops, hipStream_t st);
+void p4p_prof_end(hipStream_t st);

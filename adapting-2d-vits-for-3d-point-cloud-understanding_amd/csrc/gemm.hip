@@ -124,6 +124,11 @@ extern "C" int p4p_gemm_tn_bf16(int epi, const void* A, const void* W, void* out
     p.A = (const __bf16*)A; p.W = (const __bf16*)W; p.out = out; p.bias = bias; p.resid = resid;
     p.pre = (__bf16*)pre; p.rowgrp = rowgrp; p.stats = stats; p.M = M; p.N = N; p.K = K; p.group = group;
     hipStream_t st = (hipStream_t)stream;
+    struct ProfScope {      // gemm_tn: brackets the (one or two, when the tail is peeled) launches of this call
+        hipStream_t s; bool on;
+        ProfScope(double fl, hipStream_t s_) : s(s_), on(p4p_prof_begin(2, fl, s_)) {}
+        ~ProfScope() { if (on) p4p_prof_end(s); }
+    } prof_scope(2.0 * M * N * K, st);
     switch (epi) {
         case EPI_BF16: return launch_tn<EPI_BF16>(p, st);
         case EPI_BF16_GELU: return launch_tn<EPI_BF16_GELU>(p, st);
@@ -332,10 +337,12 @@ extern "C" int p4p_gemm_wgrad_bf16(const void* G, const void* A, float* dW, floa
         q.steps_per_split = wgrad3_steps_per_split(M, N, K);
         int splits3 = ceil_div(ceil_div(M, 32), q.steps_per_split);
         q.out = workspace;
+        const bool prof = p4p_prof_begin(1, 2.0 * M * N * K, st);
         if (wgrad3_wide(K))
             hipLaunchKernelGGL(gemm_wgrad3_kernel<256>, dim3((N / W3_BN) * (K / 256), splits3), dim3(512), 0, st, q);
         else
             hipLaunchKernelGGL(gemm_wgrad3_kernel<128>, dim3((N / W3_BN) * (K / W3_BK), splits3), dim3(256), 0, st, q);
+        if (prof) p4p_prof_end(st);
         P4P_LAUNCH_CHECK();
         long long n = (long long)N * K;
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(n / 4, 256)), dim3(256), 0, st, workspace, dW, n, splits3,

@@ -94,52 +94,36 @@ class Stepper:
 
 
 def instrumented_roofline(stepper, batch, steps):
-    """HIP events around every bf16 MFMA GEMM launch (forward, dgrad: gemm_tn_kernel; wgrad:
-    gemm_wgrad_kernel) during `steps` extra training steps; algorithmic FLOPs = 2 M N K per launch."""
-    from p4p_amd import ops
-    rec = []
-    orig_tn, orig_wg = ops.gemm_tn, ops.gemm_wgrad
-
-    def tn(a, w, epilogue=ops.EPI_BF16, **kw):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        out = orig_tn(a, w, epilogue, **kw)
-        e.record()
-        rec.append((f'gemm_tn_kernel<{epilogue}>', 2.0 * a.shape[0] * w.shape[0] * a.shape[1], s, e))
-        return out
-
-    def wg(g, a, **kw):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        out = orig_wg(g, a, **kw)
-        e.record()
-        rec.append(('gemm_wgrad_kernel', 2.0 * g.shape[0] * g.shape[1] * a.shape[1], s, e))
-        return out
-
-    ops.gemm_tn, ops.gemm_wgrad = tn, wg
-    try:
+    """Roofline of the dominant kernel, measured live: the library brackets exactly that kernel's launch with
+    HIP events on the launch stream (include/p4p_hip.h: p4p_prof_enable / p4p_prof_collect) during `steps`
+    extra training steps; algorithmic FLOPs = 2 M N K per launch.  Kind 1 = weight-gradient GEMM main kernel
+    (gemm_wgrad3_kernel, the kernel with the largest total time in profiles/), kind 2 = all gemm_tn launches."""
+    import ctypes
+    from p4p_amd import _lib
+    lib = _lib.lib()
+    res = {}
+    for kind, name in ((1, 'gemm_wgrad3_kernel'), (2, 'gemm_tn (all tile configs / epilogues)')):
+        lib.p4p_prof_enable(kind)
         for _ in range(steps):
             stepper.step(*batch)
         torch.cuda.synchronize()
-    finally:
-        ops.gemm_tn, ops.gemm_wgrad = orig_tn, orig_wg
-    agg = {}
-    for name, fl, s, e in rec:
-        a = agg.setdefault(name, [0.0, 0.0, 0])
-        a[0] += fl
-        a[1] += s.elapsed_time(e) * 1e-3
-        a[2] += 1
-    dom = max(agg, key=lambda k: agg[k][1])
-    fl, t, n = agg[dom]
-    all_fl, all_t = sum(v[0] for v in agg.values()), sum(v[1] for v in agg.values())
+        out = (ctypes.c_double * 3)()
+        rc = lib.p4p_prof_collect(out)
+        assert rc == 0
+        res[kind] = {'name': name, 'ms': out[0], 'launches': out[1], 'flops': out[2]}
+    agg_fl = sum(r['flops'] for r in res.values())
+    agg_ms = sum(r['ms'] for r in res.values())
+    dom = max(res.values(), key=lambda r: r['ms'] if r['name'].startswith('gemm_wgrad3') else 0)
+    ach = dom['flops'] / (dom['ms'] * 1e-3) * 1e-12
     return {
-        'bound': 'mfma', 'kernel': dom, 'achieved': fl / t * 1e-12, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': fl / t * 1e-12 / PEAK_BF16_TFLOPS, 'traffic': None,
-        'avg_launch_us': t / n * 1e6, 'launches_per_step': n / steps, 'flop_per_launch': fl / n,
-        'all_mfma_gemms': {'achieved': all_fl / all_t * 1e-12, 'frac': all_fl / all_t * 1e-12 / PEAK_BF16_TFLOPS,
-                           'time_per_step_ms': all_t / steps * 1e3},
-        'per_kernel': {k: {'TFLOP/s': v[0] / v[1] * 1e-12, 'ms_per_step': v[1] / steps * 1e3, 'launches': v[2] // steps}
-                       for k, v in sorted(agg.items())},
+        'bound': 'mfma', 'kernel': dom['name'], 'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+        'frac': ach / PEAK_BF16_TFLOPS, 'traffic': None,
+        'avg_launch_us': dom['ms'] / dom['launches'] * 1e3, 'launches_per_step': dom['launches'] / steps,
+        'flop_per_launch': dom['flops'] / dom['launches'], 'ms_per_step': dom['ms'] / steps,
+        'all_mfma_gemms': {'achieved': agg_fl / (agg_ms * 1e-3) * 1e-12,
+                           'frac': agg_fl / (agg_ms * 1e-3) * 1e-12 / PEAK_BF16_TFLOPS, 'ms_per_step': agg_ms / steps},
+        'per_kernel': {r['name']: {'TFLOP/s': r['flops'] / (r['ms'] * 1e-3) * 1e-12, 'ms_per_step': r['ms'] / steps,
+                                   'launches_per_step': r['launches'] / steps} for r in res.values()},
     }
 
 

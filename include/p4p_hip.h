@@ -141,6 +141,14 @@ int p4p_embed_stage1_bwd(const float* points, const float* feats, const int32_t*
                          const float* save_invstd, float* dW1, float* dW2, float* db2, float* dgamma, float* dbeta,
                          float beta_acc, int B, int N, int S, int k, int C1, void* stream);
 
+/* ---- measurement aid (bench.py roofline): HIP events on the launch stream around exactly the main kernel of
+ * kind 1 (weight-gradient GEMM) or 2 (gemm_tn).  collect(): out[0] = total ms, out[1] = launches, out[2] = FLOPs. */
+int p4p_prof_enable(int kind);
+int p4p_prof_collect(double* out);
+/* experiment switches (tools/gemm_bench.py): tile configuration overrides, 0 = automatic */
+int p4p_set_gemm_variant(int v);
+int p4p_set_wgrad_wide(int v);
+
 #ifdef __cplusplus
 }
 #endif
