@@ -24,7 +24,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md)
-FLOP_PER_CLOUD = {1024: 149.6e9, 2048: 313.2e9}     # fwd+bwd algorithmic FLOPs, SURVEY.md section 8d
+def flop_per_cloud(points, D, L, k=16):
+    """fwd+bwd algorithmic FLOPs per cloud, SURVEY.md section 8d: 3 x (S k 920,576 + L (24 T D^2 + 4 T^2 D))."""
+    S = points // 4
+    T = S + 1
+    return 3.0 * (S * k * 920576.0 + L * (24.0 * T * D * D + 4.0 * T * T * D))
 
 
 def log(msg):
@@ -229,17 +233,20 @@ def main():
     if rank == 0:
         clouds = args.batch * world * args.steps
         value = clouds / elapsed
-        fl = FLOP_PER_CLOUD.get(args.points)
+        from p4p_amd.vit import parse_model_name
+        vd, vl, vh, _, _ = parse_model_name(args.vit)
+        fl = flop_per_cloud(args.points, vd, vl)
+        fam = {192: 'ViT-Ti', 384: 'ViT-S', 768: 'ViT-B', 1024: 'ViT-L'}.get(vd, f'ViT(D={vd})')
         out = {
-            'metric': f'point-clouds/sec fwd+bwd (train step), ModelNet40-shaped N={args.points} ViT-B',
+            'metric': f'point-clouds/sec fwd+bwd (train step), ModelNet40-shaped N={args.points} {fam}',
             'value': value, 'unit': 'point-clouds/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': f'Pix4Point {args.vit} (D={args.dim}, 12 blocks) N={args.points} k=16, '
+            'config': {'workload': f'Pix4Point {args.vit} (D={vd}, {vl} blocks, {vh} heads) N={args.points} k=16, '
                                    f'{args.classes} classes, batch {args.batch}/GPU; step = zero_grad+fwd+CE+bwd'
                                    f'{"+RCCL all-reduce" if distributed else ""}+clip_grad_norm+AdamW(fused)',
                        'global_batch': args.batch * world, 'points': args.points, 'parallelism': f'dp{world}',
-                       'final_loss': loss_val},
+                       'final_loss': loss_val, 'algorithmic_gflop_per_cloud': fl * 1e-9},
             'algorithmic_tflops_per_gpu': (value / world * fl * 1e-12) if fl else None,
             'mfma_frac_whole_step': (value / world * fl * 1e-12 / PEAK_BF16_TFLOPS) if fl else None,
         }
