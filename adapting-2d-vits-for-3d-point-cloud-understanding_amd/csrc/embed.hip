@@ -82,13 +82,22 @@ struct FoldParams {
 
 __global__ __launch_bounds__(256) void embed_fold_kernel(FoldParams p) {
     __shared__ double sm[NMOM];
+    __shared__ double smp[8][32];
     __shared__ float w1s[256 * X6];
     const int c = threadIdx.x;
     for (int i = c; i < p.C1 * X6; i += 256) w1s[i] = p.W1[i];
+    {   // partial moments -> sm: 32 moment slots x 8 row lanes, fixed order (reproducible), fp64
+        const int mi = c & 31, rl = c >> 5;
+        double s = 0.0;
+        if (p.training && mi < NMOM)
+            for (int r = rl; r < p.mom_rows; r += 8) s += (double)p.mom_partial[(size_t)r * NMOM + mi];
+        smp[rl][mi] = s;
+    }
+    __syncthreads();
     if (c < NMOM) {
         double s = 0.0;
-        if (p.training)
-            for (int r = 0; r < p.mom_rows; ++r) s += (double)p.mom_partial[(size_t)r * NMOM + c];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += smp[k][c];
         sm[c] = s;
     }
     __syncthreads();

@@ -45,6 +45,13 @@ __device__ __forceinline__ void phi_and_e(float x, float& Phi, float& e) {
 }
 __device__ __forceinline__ float gelu_f(float x) { float P, e; phi_and_e(x, P, e); return x * P; }
 __device__ __forceinline__ float dgelu_f(float x) { float P, e; phi_and_e(x, P, e); return P + x * 0.3989422804014327f * e; }
+// both at once for the forward epilogue: the backward epilogue then only multiplies by the stored derivative
+__device__ __forceinline__ void gelu_and_dgelu(float x, float& y, float& dy) {
+    float P, e;
+    phi_and_e(x, P, e);
+    y = x * P;
+    dy = P + x * 0.3989422804014327f * e;
+}
 
 // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
 // contiguous run of tiles; consecutive tiles sweep N for a fixed M panel.  Bijective for any grid size.
@@ -173,17 +180,24 @@ void gemm_tn2_kernel(GemmParams p) {
                 continue;
             }
             if (EPI == EPI_BF16_GELU) {
-                // pre-activation goes out directly (it is only read back by the backward pass)
+                // `pre` receives gelu'(h) (only the backward pass reads it, as a plain multiplier)
+                f32x4 y, dy;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float yy, dd;                      // (vector elements cannot bind to float&)
+                    gelu_and_dgelu(v[r], yy, dd);
+                    y[r] = yy;
+                    dy[r] = dd;
+                }
                 if (p.pre && ok) {
-                    bf16x4 w = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                    bf16x4 w = {f2bf(dy[0]), f2bf(dy[1]), f2bf(dy[2]), f2bf(dy[3])};
                     *reinterpret_cast<bf16x4*>(p.pre + o) = w;
                 }
-                v = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+                v = y;
             } else if (EPI == EPI_BF16_DGELU) {
                 if (ok) {
                     bf16x4 h = *reinterpret_cast<const bf16x4*>(p.pre + o);
-                    v = f32x4{v[0] * dgelu_f(bf2f(h[0])), v[1] * dgelu_f(bf2f(h[1])), v[2] * dgelu_f(bf2f(h[2])),
-                              v[3] * dgelu_f(bf2f(h[3]))};
+                    v = f32x4{v[0] * bf2f(h[0]), v[1] * bf2f(h[1]), v[2] * bf2f(h[2]), v[3] * bf2f(h[3])};
                 }
             } else if (EPI == EPI_BF16_ROWGROUP) {
                 if (ok) v += *reinterpret_cast<const f32x4*>(p.rowgrp + (size_t)(m / p.group) * p.N + n);

@@ -225,31 +225,42 @@ __global__ __launch_bounds__(BN_ * 2, 2) void gemm_tn3_kernel(GemmParams p) {
         }
         __syncthreads();
     }
-    if (EPI == EPI_BF16_GELU && p.pre) {
+    if (EPI == EPI_BF16_GELU) {
+        // one pass over the accumulators: y = gelu(h) replaces h IN PLACE (fp32), gelu'(h) goes to the staging tile
+        // (`pre` receives it: the backward epilogue then only multiplies)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const f32x4 v = acc[i][j] + bias4[i];
-                bf16x4 w = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-                *reinterpret_cast<bf16x4*>(lds + (wm * 128 + j * 16 + li) * CS16 + (wn * 64 + i * 16 + g * 4) * 2) = w;
+                f32x4 v = acc[i][j] + bias4[i], dy;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float yy, dd;
+                    gelu_and_dgelu(v[r], yy, dd);
+                    v[r] = yy;
+                    dy[r] = dd;
+                }
+                acc[i][j] = v;
+                if (p.pre) {
+                    bf16x4 w = {f2bf(dy[0]), f2bf(dy[1]), f2bf(dy[2]), f2bf(dy[3])};
+                    *reinterpret_cast<bf16x4*>(lds + (wm * 128 + j * 16 + li) * CS16 + (wn * 64 + i * 16 + g * 4) * 2) = w;
+                }
             }
-        __syncthreads();
-        copy_out(p.pre);
-        __syncthreads();
+        if (p.pre) {
+            __syncthreads();
+            copy_out(p.pre);
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             char* slot = lds + (wm * 128 + j * 16 + li) * CS16 + (wn * 64 + i * 16 + g * 4) * 2;
-            f32x4 v = acc[i][j] + bias4[i];
-            if (EPI == EPI_BF16_GELU) {
-                v = f32x4{gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
-            } else if (EPI == EPI_BF16_DGELU) {
+            f32x4 v = EPI == EPI_BF16_GELU ? acc[i][j] : acc[i][j] + bias4[i];      // GELU: already activated above
+            if (EPI == EPI_BF16_DGELU) {
                 const bf16x4 h = *reinterpret_cast<const bf16x4*>(slot);
-                v = f32x4{v[0] * dgelu_f(bf2f(h[0])), v[1] * dgelu_f(bf2f(h[1])), v[2] * dgelu_f(bf2f(h[2])),
-                          v[3] * dgelu_f(bf2f(h[3]))};
+                v = f32x4{v[0] * bf2f(h[0]), v[1] * bf2f(h[1]), v[2] * bf2f(h[2]), v[3] * bf2f(h[3])};
             }
             bf16x4 w = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
             *reinterpret_cast<bf16x4*>(slot) = w;

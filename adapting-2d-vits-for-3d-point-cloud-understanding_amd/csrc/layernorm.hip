@@ -156,25 +156,28 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(const void* _
 }
 
 // out[c] = beta*out[c] + sum_r part[r*stride + c]   for c < ncols  (fixed order: reproducible).
-// 256 threads = 32 columns x 8 row lanes; each lane strides the rows by 8, partials meet in LDS.
+// 256 threads = 16 columns x 16 row lanes (64-B row segments): ncols/16 blocks keep >100 CUs busy for the
+// 768..2304-column reductions of the encoder; each lane strides the rows by 16, partials meet in LDS.
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                          int nrows, long long stride, int ncols, float beta) {
-    __shared__ float red[8][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + tx;
+    __shared__ float red[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + tx;
     float s0 = 0.f, s1 = 0.f;
     if (c < ncols) {
         int r = ty;
-        for (; r + 8 < nrows; r += 16) {
+        for (; r + 16 < nrows; r += 32) {
             s0 += part[(size_t)r * stride + c];
-            s1 += part[(size_t)(r + 8) * stride + c];
+            s1 += part[(size_t)(r + 16) * stride + c];
         }
         if (r < nrows) s0 += part[(size_t)r * stride + c];
     }
     red[ty][tx] = s0 + s1;
     __syncthreads();
     if (ty == 0 && c < ncols) {
-        float s = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) + ((red[4][tx] + red[5][tx]) + (red[6][tx] + red[7][tx]));
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][tx];
         out[c] = beta != 0.f ? beta * out[c] + s : s;
     }
 }
@@ -219,7 +222,7 @@ extern "C" int p4p_layernorm_bwd(const void* dy, int dy_is_f32, const float* xin
     P4P_LAUNCH_CHECK();
     if (dgamma && dbeta == dgamma + D && (!dxsum || dxsum == dgamma + 2 * D)) {   // contiguous destination: one launch
         const int rows = dxsum ? 3 : 2;
-        hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(rows * D, 32)), dim3(256), 0, st, partial, dgamma, blocks,
+        hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(rows * D, 16)), dim3(256), 0, st, partial, dgamma, blocks,
                            (long long)3 * D, rows * D, beta_acc);
         P4P_LAUNCH_CHECK();
         return 0;
@@ -227,7 +230,7 @@ extern "C" int p4p_layernorm_bwd(const void* dy, int dy_is_f32, const float* xin
     float* dst[3] = {dgamma, dbeta, dxsum};
     for (int i = 0; i < 3; ++i) {
         if (!dst[i]) continue;
-        hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(D, 32)), dim3(256), 0, st, partial + (size_t)i * D, dst[i],
+        hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(D, 16)), dim3(256), 0, st, partial + (size_t)i * D, dst[i],
                            blocks, (long long)3 * D, D, beta_acc);
         P4P_LAUNCH_CHECK();
     }
@@ -237,7 +240,7 @@ extern "C" int p4p_layernorm_bwd(const void* dy, int dy_is_f32, const float* xin
 extern "C" int p4p_colreduce_f32(const float* part, float* out, int nrows, long long stride, int ncols, float beta,
                                  void* stream) {
     P4P_CHECK(part && out && nrows >= 1 && ncols >= 1, "p4p_colreduce_f32: bad arguments");
-    hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(ncols, 32)), dim3(256), 0, (hipStream_t)stream, part, out,
+    hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(ncols, 16)), dim3(256), 0, (hipStream_t)stream, part, out,
                        nrows, stride, ncols, beta);
     P4P_LAUNCH_CHECK();
     return 0;

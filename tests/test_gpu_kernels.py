@@ -177,7 +177,9 @@ def test_gemm_tn_epilogues_random():
     ref = a.float() @ w.float().t() + bias
     out, pre = ops.gemm_tn(a, w, ops.EPI_BF16_GELU, bias=bias, want_pre=True)
     # tolerance: one bf16 rounding of the output (2^-8 relative) on top of fp32 accumulation
-    torch.testing.assert_close(pre.float(), ref, rtol=1e-2, atol=1e-2)
+    xg = ref.clone().requires_grad_(True)
+    torch.nn.functional.gelu(xg).sum().backward()
+    torch.testing.assert_close(pre.float(), xg.grad, rtol=1e-2, atol=1e-2)        # `pre` holds gelu'(h)
     torch.testing.assert_close(out.float(), torch.nn.functional.gelu(ref), rtol=1e-2, atol=1e-2)
     # the fast erf (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7) against libm on a dense grid incl. the tails
     xs = torch.linspace(-9, 9, 128 * 64, device=DEV).view(128, 64)
@@ -186,9 +188,7 @@ def test_gemm_tn_epilogues_random():
     gl = ops.gemm_tn(xb, eye, ops.EPI_BF16_GELU, bias=torch.zeros(64, device=DEV))
     torch.testing.assert_close(gl.float(), torch.nn.functional.gelu(xb.float()), rtol=8e-3, atol=1e-6)
     dg = ops.gemm_tn(a, w, ops.EPI_BF16_DGELU, pre=pre)
-    x = pre.float().requires_grad_(True)
-    torch.nn.functional.gelu(x).sum().backward()
-    torch.testing.assert_close(dg.float(), (a.float() @ w.float().t()) * x.grad, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(dg.float(), (a.float() @ w.float().t()) * pre.float(), rtol=2e-2, atol=2e-2)
     # row-group broadcast + column statistics
     grp = 7
     rg = torch.randn(M // grp, N, generator=g).to(DEV)
