@@ -92,6 +92,53 @@ __device__ __forceinline__ float xor_lanes_sum(float v) {
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
+// One K/V tile of the forward pass for a wave's 16 queries.  MASK is a compile-time flag: only the ragged last
+// tile pays for the key masking (as a runtime condition hipcc if-converts it into 16 v_cndmask per tile).
+template <bool MASK>
+__device__ __forceinline__ void attn_fwd_tile(const char* kt_lds, const char* vt_lds, const bf16x8 (&qf)[2], f32x4 (&o)[4],
+                                              float& m, float& lsum, float c, int key0, int T, int lane) {
+    const int g = lane >> 4;
+    f32x4 s[4];
+#pragma unroll
+    for (int k16 = 0; k16 < 4; ++k16) {
+        s[k16] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            s[k16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(kt_lds, k16, ks, lane), qf[ks], s[k16], 0, 0, 0);
+    }
+    if (MASK) {
+#pragma unroll
+        for (int k16 = 0; k16 < 4; ++k16)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (key0 + k16 * 16 + 4 * g + r >= T) s[k16][r] = -INFINITY;
+    }
+    float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+#pragma unroll
+    for (int k16 = 1; k16 < 4; ++k16) mx = fmaxf(mx, fmaxf(fmaxf(s[k16][0], s[k16][1]), fmaxf(s[k16][2], s[k16][3])));
+    mx = xor_lanes_max(mx) * c;
+    const float mnew = fmaxf(m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+    m = mnew;
+    float ps = 0.f;
+#pragma unroll
+    for (int k16 = 0; k16 < 4; ++k16)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[k16][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[k16][r], c, -mnew));
+            ps += s[k16][r];
+        }
+    lsum = lsum * alpha + ps;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] *= alpha;
+    bf16x8 pb[2] = {pack_pair(s[0], s[1]), pack_pair(s[2], s[3])};
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+            o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(vt_lds, ss, d, lane), pb[ss], o[d], 0, 0, 0);
+}
+
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * TILE_BYTES];     // [buf][K|V]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
@@ -115,59 +162,46 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
     for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, lsum = 0.f;
 
+    // LDS-DMA sources of this lane's 2 K pieces and 2 V pieces for tile 0; a full tile further = +64 rows.
+    // Only the ragged last tile needs row clamping (stage_rows); full tiles just advance the pointers.
+    const int rin = lane >> 3, chunk = (lane & 7) ^ rin;
+    const __bf16* ksrc[2];
+    const __bf16* vsrc[2];
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+        const size_t off = (size_t)((wave * 2 + qq) * 8 + rin) * ld + chunk * 8;
+        ksrc[qq] = kbase + off;
+        vsrc[qq] = vbase + off;
+    }
+    const size_t tile_step = (size_t)64 * ld;
+    auto stage_full = [&](int kt, char* buf) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(ksrc[qq] + kt * tile_step), LDS_PTR(buf + (wave * 2 + qq) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(vsrc[qq] + kt * tile_step), LDS_PTR(buf + TILE_BYTES + (wave * 2 + qq) * 1024), 16, 0, 0);
+        }
+    };
+    auto stage_any = [&](int kt, char* buf) {
+        if ((kt + 1) * 64 <= T) stage_full(kt, buf);
+        else {
+            stage_rows(kbase, ld, kt * 64, T, buf, wave, lane);
+            stage_rows(vbase, ld, kt * 64, T, buf + TILE_BYTES, wave, lane);
+        }
+    };
+
     const int nkt = (T + 63) / 64;
-    stage_rows(kbase, ld, 0, T, lds, wave, lane);
-    stage_rows(vbase, ld, 0, T, lds + TILE_BYTES, wave, lane);
-    for (int kt = 0; kt < nkt; ++kt) {
+    const int nfull = T / 64;                                 // tiles that need no masking
+    stage_any(0, lds);
+    for (int kt = 0; kt < nfull; ++kt) {
         __syncthreads();
-        const char* kt_lds = lds + (kt & 1) * 2 * TILE_BYTES;
-        const char* vt_lds = kt_lds + TILE_BYTES;
-        if (kt + 1 < nkt) {
-            char* nxt = lds + ((kt + 1) & 1) * 2 * TILE_BYTES;
-            stage_rows(kbase, ld, (kt + 1) * 64, T, nxt, wave, lane);
-            stage_rows(vbase, ld, (kt + 1) * 64, T, nxt + TILE_BYTES, wave, lane);
-        }
-        f32x4 s[4];
-#pragma unroll
-        for (int k16 = 0; k16 < 4; ++k16) {
-            s[k16] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                s[k16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(kt_lds, k16, ks, lane), qf[ks], s[k16], 0, 0, 0);
-        }
-        if (kt == nkt - 1 && (T & 63) != 0) {              // wave-uniform: only the ragged last tile masks keys
-#pragma unroll
-            for (int k16 = 0; k16 < 4; ++k16)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (kt * 64 + k16 * 16 + 4 * g + r >= T) s[k16][r] = -INFINITY;
-        }
-        float mx = -INFINITY;                               // max of the RAW scores (c > 0 keeps the arg-max)
-#pragma unroll
-        for (int k16 = 0; k16 < 4; ++k16)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[k16][r]);
-        mx = xor_lanes_max(mx) * c;
-        const float mnew = fmaxf(m, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-        m = mnew;
-        float ps = 0.f;
-#pragma unroll
-        for (int k16 = 0; k16 < 4; ++k16)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[k16][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[k16][r], c, -mnew));   // p = 2^(c s - m)
-                ps += s[k16][r];
-            }
-        lsum = lsum * alpha + ps;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) o[d] *= alpha;
-        bf16x8 pb[2] = {pack_pair(s[0], s[1]), pack_pair(s[2], s[3])};
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int ss = 0; ss < 2; ++ss)
-                o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(vt_lds, ss, d, lane), pb[ss], o[d], 0, 0, 0);
+        const char* cur = lds + (kt & 1) * 2 * TILE_BYTES;
+        if (kt + 1 < nkt) stage_any(kt + 1, lds + ((kt + 1) & 1) * 2 * TILE_BYTES);
+        attn_fwd_tile<false>(cur, cur + TILE_BYTES, qf, o, m, lsum, c, kt * 64, T, lane);
+    }
+    if (nfull < nkt) {
+        __syncthreads();
+        const char* cur = lds + (nfull & 1) * 2 * TILE_BYTES;
+        attn_fwd_tile<true>(cur, cur + TILE_BYTES, qf, o, m, lsum, c, nfull * 64, T, lane);
     }
     const float l = xor_lanes_sum(lsum);
     const float inv = 1.0f / l;
