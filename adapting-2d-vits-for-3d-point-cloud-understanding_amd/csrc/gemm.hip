@@ -35,10 +35,10 @@ __device__ float g_zero_page[64];   // 256 B of zeros: LDS-DMA source for rows p
 static int g_gemm_variant = 0;
 extern "C" int p4p_set_gemm_variant(int v) { int o = g_gemm_variant; g_gemm_variant = v; return o; }
 
-template <int BM_, int BN_, int WAVES_M, int WAVES_N, int EPI, bool PIN = false>
+template <int BM_, int BN_, int WAVES_M, int WAVES_N, int EPI, bool PIN = false, int ABL = 0>
 static int launch_cfg(const GemmParams& p, hipStream_t st) {
     int tiles = ceil_div(p.M, BM_) * ceil_div(p.N, BN_);
-    hipLaunchKernelGGL((gemm_tn2_kernel<BM_, BN_, WAVES_M, WAVES_N, EPI, PIN>), dim3(tiles), dim3(WAVES_M * WAVES_N * 64), 0, st, p);
+    hipLaunchKernelGGL((gemm_tn2_kernel<BM_, BN_, WAVES_M, WAVES_N, EPI, PIN, ABL>), dim3(tiles), dim3(WAVES_M * WAVES_N * 64), 0, st, p);
     P4P_LAUNCH_CHECK();
     return 0;
 }
@@ -55,10 +55,11 @@ static int launch_tn(const GemmParams& p, hipStream_t st) {
         //   HBM / VALU-heavy epilogue with the other workgroup's MFMA loop
         const bool big = (long long)ceil_div(p.M, 256) * ceil_div(p.N, 128) >= 512;
         const bool big256 = p.N % 256 == 0 && (long long)ceil_div(p.M, 256) * (p.N / 256) >= 256;
-        // 256x256 tile everywhere it fits; the K-step-32 ring + LDS-staged fp32 / double-output epilogue (7) wins for
-        // the residual and GELU epilogues (proj 429 vs 381, fc1 606 vs 538, fc2 801 vs 778 TFLOP/s), the
-        // mid-tile-barrier schedule (3) for plain bf16 / dGELU outputs (qkv 933 vs 868, dfc1 1065 vs 997)
-        if (big256) v = (EPI == EPI_F32_RESID || EPI == EPI_BF16_GELU) ? 7 : 3;
+        // 256x256 tile everywhere it fits.  Measured (tools/gemm_bench.py, TFLOP/s, ViT-B shapes): the K-step-32 ring
+        // with the hand-interleaved issue order {LDS-DMA, 4 MFMA, 3 reads, 4 MFMA} (8) wins for every fused epilogue
+        // (proj 438 vs 380, fc2 852 vs 782, dfc2 691 vs 671, fc1 586 vs 569) and for long K (dfc1 1052 vs 1018);
+        // the mid-tile-barrier schedule (3) keeps the plain bf16 epilogue at K = 768 (qkv 911 vs 884)
+        if (big256) v = (EPI == EPI_BF16 && p.K < 1536) ? 3 : 8;
         else if (p.N % T3_BN == 0 && big) v = 4;
         else v = 1;
     }
@@ -66,8 +67,8 @@ static int launch_tn(const GemmParams& p, hipStream_t st) {
         // Grid quantisation: with few rounds of big tiles (M = 256*257 and N = 768 give 771 tiles of 256x256 on
         // 256 CUs = 3 rounds + 3 tiles -> a 4th round for 0.4% of the work, measured -15..20%), peel the last
         // row tile(s) off and run them with the 128x128 configuration (many small workgroups, one short round).
-        if ((v == 3 || v == 4 || v == 5 || v == 7) && p.M % 256 == 0) {
-            const int bn = (v == 3 || v == 7) ? 256 : T3_BN, slots = (v == 3 || v == 7) ? 256 : 512;
+        if ((v == 3 || v == 4 || v == 5 || v == 7 || v == 8) && p.M % 256 == 0) {
+            const int bn = (v == 3 || v == 7 || v == 8) ? 256 : T3_BN, slots = (v == 3 || v == 7 || v == 8) ? 256 : 512;
             const int tiles_n = ceil_div(p.N, bn), tiles_m = p.M / 256;
             const long long total = (long long)tiles_m * tiles_n;
             const long long rounds = total / slots, rem = total % slots;
@@ -97,11 +98,18 @@ static int launch_tn(const GemmParams& p, hipStream_t st) {
             P4P_LAUNCH_CHECK();
             return 0;
         }
-        if (v == 7 && p.N % 256 == 0) {          // 256 x 256, 8 waves, K-step 32 ring (1 workgroup per CU)
+        if ((v == 7 || v == 8) && p.N % 256 == 0) {          // 256 x 256, 8 waves, K-step 32 ring (1 workgroup per CU)
             int tiles = ceil_div(p.M, T3_BM) * (p.N / 256);
-            hipLaunchKernelGGL((gemm_tn3_kernel<EPI, false, 256>), dim3(tiles), dim3(512), 0, st, p);
+            if (v == 8) hipLaunchKernelGGL((gemm_tn3_kernel<EPI, false, 256, true>), dim3(tiles), dim3(512), 0, st, p);
+            else hipLaunchKernelGGL((gemm_tn3_kernel<EPI, false, 256>), dim3(tiles), dim3(512), 0, st, p);
             P4P_LAUNCH_CHECK();
             return 0;
+        }
+        if (EPI == EPI_BF16) {     // timing-only ablations of the 256x256 loop (results are wrong by construction)
+            if (v == 21) return launch_cfg<256, 256, 2, 4, EPI_BF16, false, 1>(p, st);
+            if (v == 22) return launch_cfg<256, 256, 2, 4, EPI_BF16, false, 2>(p, st);
+            if (v == 23) return launch_cfg<256, 256, 2, 4, EPI_BF16, false, 3>(p, st);
+            if (v == 31) return launch_cfg<256, 256, 2, 4, EPI_BF16, false, 4>(p, st);
         }
         if (v == 6) return launch_cfg<64, 64, 2, 2, EPI>(p, st);
         if (v == 3) return launch_cfg<256, 256, 2, 4, EPI>(p, st);
@@ -296,7 +304,7 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
 }
 
 static bool wgrad_use_v3(int M, int N, int K) { return N % W3_BN == 0 && K % W3_BK == 0 && M >= 4096; }
-static int g_wgrad_wide = 1;
+static int g_wgrad_wide = 2;      // 0: 256x128 tiles, 1: 256x256, 2: 256x256 with the hand-interleaved issue order
 extern "C" int p4p_set_wgrad_wide(int v) { int o = g_wgrad_wide; g_wgrad_wide = v; return o; }
 static bool wgrad3_wide(int K) { return g_wgrad_wide && K % 256 == 0; }      // 256x256 tile, 8 waves, 1 workgroup per CU
 static int wgrad3_steps_per_split(int M, int N, int K) {
@@ -338,7 +346,9 @@ extern "C" int p4p_gemm_wgrad_bf16(const void* G, const void* A, float* dW, floa
         int splits3 = ceil_div(ceil_div(M, 32), q.steps_per_split);
         q.out = workspace;
         const bool prof = p4p_prof_begin(1, 2.0 * M * N * K, st);
-        if (wgrad3_wide(K))
+        if (wgrad3_wide(K) && g_wgrad_wide == 2)
+            hipLaunchKernelGGL((gemm_wgrad3_kernel<256, true>), dim3((N / W3_BN) * (K / 256), splits3), dim3(512), 0, st, q);
+        else if (wgrad3_wide(K))
             hipLaunchKernelGGL(gemm_wgrad3_kernel<256>, dim3((N / W3_BN) * (K / 256), splits3), dim3(512), 0, st, q);
         else
             hipLaunchKernelGGL(gemm_wgrad3_kernel<128>, dim3((N / W3_BN) * (K / W3_BK), splits3), dim3(256), 0, st, q);

@@ -60,7 +60,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
-template <int BM_, int BN_, int WAVES_M, int WAVES_N, int EPI, bool PIN>
+template <int BM_, int BN_, int WAVES_M, int WAVES_N, int EPI, bool PIN, int ABL = 0>   // ABL: timing-only ablations (bit0: no LDS-DMA in the loop, bit1: no fragment reads); bit2: interleaved issue order
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (WAVES_M * WAVES_N * 64 * ((2 * (BM_ + BN_) * 128) > 81920 ? 1 : 2)) / 256)
 void gemm_tn2_kernel(GemmParams p) {
     constexpr int NW = WAVES_M * WAVES_N, NT_ = NW * 64;
@@ -129,19 +129,39 @@ void gemm_tn2_kernel(GemmParams p) {
     __syncthreads();
     if (nk > 1) stage(1, lds + STAGE);
     read_frags(lds, 0, fa0, fw0);
+    if (ABL & 2) read_frags(lds, 1, fa1, fw1);
     for (int kt = 0; kt < nk; ++kt) {
         char* cur = lds + (kt & 1) * STAGE;
         char* nxt = lds + ((kt + 1) & 1) * STAGE;
-        read_frags(cur, 1, fa1, fw1);
+        if (!(ABL & 2)) read_frags(cur, 1, fa1, fw1);
         if (PIN) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); }
         mma(fa0, fw0);
         if (PIN) { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); }
         __syncthreads();                       // tile kt+1 landed everywhere; buffer `cur` is no longer read
-        if (kt + 2 < nk) stage(kt + 2, cur);
-        if (kt + 1 < nk) read_frags(nxt, 0, fa0, fw0);
+        if (kt + 2 < nk && !(ABL & 1)) stage(kt + 2, cur);
+        if (kt + 1 < nk && !(ABL & 2)) read_frags(nxt, 0, fa0, fw0);
+        if (ABL & 2) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(fa0[j]), "+v"(fa1[j]));
+#pragma unroll
+            for (int i = 0; i < NTL; ++i) asm volatile("" : "+v"(fw0[i]), "+v"(fw1[i]));
+        }
         if (PIN) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); }
         mma(fa1, fw1);
         if (PIN) { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); }
+        if (ABL & 4) {
+            // issue order of this phase: one LDS-DMA, then MFMAs, then a couple of fragment reads, more MFMAs ...
+            // so a wave stuck in a 60-180-cycle LDS-DMA issue always has MFMAs queued in the pipe behind it
+            constexpr int NMFMA = MT * NTL, NDMA = PPW, NRD = MT + NTL;
+            constexpr int G = NDMA > 0 ? NDMA : 1;
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                       // 1 VMEM read (LDS-DMA)
+                __builtin_amdgcn_sched_group_barrier(0x008, NMFMA / G / 2, 0);           // MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, (NRD + G - 1) / G, 0);       // fragment reads
+                __builtin_amdgcn_sched_group_barrier(0x008, NMFMA / G - NMFMA / G / 2, 0);
+            }
+        }
     }
 
     // ---------------------------------------------------------------------------------------------

@@ -34,7 +34,7 @@ struct T3Frags {
     bf16x8 w[4];
 };
 
-template <int EPI, bool PAIR, int BN_>
+template <int EPI, bool PAIR, int BN_, bool ILV = false>
 __global__ __launch_bounds__(BN_ * 2, 2) void gemm_tn3_kernel(GemmParams p) {
     constexpr int NWN = BN_ / 64, NW = 2 * NWN, NTHR = NW * 64;      // waves: 2 (M) x NWN (N), each 128 x 64
     constexpr int T3_STAGE = (T3_BM + BN_) * 64;                      // 24 / 32 KiB per K-step of 32
@@ -142,10 +142,34 @@ __global__ __launch_bounds__(BN_ * 2, 2) void gemm_tn3_kernel(GemmParams p) {
     // {LDS-DMA, fragment prefetch, 32 MFMAs, counted wait, barrier} without conservative waits
 #define T3_FULL(KT, FC, FN)                                                               \
     {                                                                                     \
-        stage((KT) + 3, cur);                                                             \
-        read_frags(nxt, FN);                                                              \
-        __builtin_amdgcn_sched_barrier(0);   /* keep the prefetch AHEAD of the MFMAs */   \
-        mma(FC);                                                                          \
+        if (!ILV) {                                                                       \
+            stage((KT) + 3, cur);                                                         \
+            read_frags(nxt, FN);                                                          \
+            __builtin_amdgcn_sched_barrier(0);   /* keep the prefetch AHEAD of the MFMAs */ \
+            mma(FC);                                                                      \
+        } else {                                                                          \
+            /* hand-pinned issue order (BN_=256: 4 groups of {1 LDS-DMA, 4 MFMA, 3 fragment reads, 4 MFMA}): an     \
+               LDS-DMA issue holds the wave 60-180 cycles, so MFMAs are always queued in the pipe behind it */     \
+            _Pragma("unroll") for (int qq = 0; qq < 4; ++qq) {                            \
+                if (qq < T3_PPW)                                                          \
+                    __builtin_amdgcn_global_load_lds(GLB_PTR(src[qq] + ((KT) + 3) * 32),  \
+                                                     LDS_PTR(cur + (wave * T3_PPW + qq) * 1024), 16, 0, 0); \
+                if (T3_PPW > 4 && qq < T3_PPW - 4)                                        \
+                    __builtin_amdgcn_global_load_lds(GLB_PTR(src[qq + 4] + ((KT) + 3) * 32), \
+                                                     LDS_PTR(cur + (wave * T3_PPW + qq + 4) * 1024), 16, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);                                        \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                             \
+                    acc[qq][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FC.w[qq], FC.a[j], acc[qq][j], 0, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);                                        \
+                FN.a[2 * qq] = *reinterpret_cast<const bf16x8*>(nxt + a_off + (2 * qq) * 1024);     \
+                FN.a[2 * qq + 1] = *reinterpret_cast<const bf16x8*>(nxt + a_off + (2 * qq + 1) * 1024); \
+                FN.w[qq] = *reinterpret_cast<const bf16x8*>(nxt + w_off + qq * 1024);    \
+                __builtin_amdgcn_sched_barrier(0);                                        \
+                _Pragma("unroll") for (int j = 4; j < 8; ++j)                             \
+                    acc[qq][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FC.w[qq], FC.a[j], acc[qq][j], 0, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);                                        \
+            }                                                                             \
+        }                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                \
         WAIT_VM(T3_PPW);                                                                  \
         WAIT_LGKM0();                                                                     \

@@ -37,7 +37,7 @@ __device__ __forceinline__ bf16x8 w3_tr(int lo, int hi) {
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <int BK_>
+template <int BK_, bool ILV = false>
 __global__ __launch_bounds__(BK_ * 2, 2) void gemm_wgrad3_kernel(W3Params p) {
     constexpr int NWK = BK_ / 64, NW = 2 * NWK;                       // waves: 2 (n) x NWK (k), each 128 x 64
     constexpr int W3_STAGE = 32 * (W3_BN + BK_) * 2;                   // 24 / 32 KiB per 32-row step
@@ -157,10 +157,35 @@ __global__ __launch_bounds__(BK_ * 2, 2) void gemm_wgrad3_kernel(W3Params p) {
     char *cur = s0, *nxt = s1, *nn = s2;
 #define W3_FULL(KT, FC, FN)                                                               \
     {                                                                                     \
-        stage_fast((KT) + 3, cur);                                                        \
-        read_frags((int)(nxt - lds), FN);                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                \
-        mma(FC);                                                                          \
+        if (!ILV) {                                                                       \
+            stage_fast((KT) + 3, cur);                                                    \
+            read_frags((int)(nxt - lds), FN);                                             \
+            __builtin_amdgcn_sched_barrier(0);                                            \
+            mma(FC);                                                                      \
+        } else {                                                                          \
+            /* hand-pinned issue order, 4 groups of {LDS-DMA, 4 MFMA, 6 transposing reads, 4 MFMA} */ \
+            const int bo = (int)(nxt - lds);                                              \
+            int bgl = lds_base + bo + g_lo, bgh = lds_base + bo + g_hi;                    \
+            int bal = lds_base + bo + a_lo, bah = lds_base + bo + a_hi;                    \
+            asm volatile("" : "+v"(bgl), "+v"(bgh), "+v"(bal), "+v"(bah));                \
+            _Pragma("unroll") for (int qq = 0; qq < 4; ++qq) {                            \
+                _Pragma("unroll") for (int q2 = qq; q2 < W3_PPW; q2 += 4)                 \
+                    __builtin_amdgcn_global_load_lds(                                     \
+                        GLB_PTR((q2 < GPW ? gbase : abase) + (size_t)((KT) + 3) * 64 * (q2 < GPW ? p.N : p.K) + soff[q2]), \
+                        LDS_PTR(cur + lds_piece(q2)), 16, 0, 0);                          \
+                __builtin_amdgcn_sched_barrier(0);                                        \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                             \
+                    acc[qq][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FC.a[qq], FC.g[j], acc[qq][j], 0, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);                                        \
+                FN.g[2 * qq] = w3_tr(bgl ^ ((2 * qq) << 5), bgh ^ ((2 * qq) << 5));        \
+                FN.g[2 * qq + 1] = w3_tr(bgl ^ ((2 * qq + 1) << 5), bgh ^ ((2 * qq + 1) << 5)); \
+                FN.a[qq] = w3_tr(bal ^ (qq << 5), bah ^ (qq << 5));                        \
+                __builtin_amdgcn_sched_barrier(0);                                        \
+                _Pragma("unroll") for (int j = 4; j < 8; ++j)                             \
+                    acc[qq][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FC.a[qq], FC.g[j], acc[qq][j], 0, 0, 0); \
+                __builtin_amdgcn_sched_barrier(0);                                        \
+            }                                                                             \
+        }                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                \
         WAIT_VM(W3_PPW);                                                                  \
         WAIT_LGKM0();                                                                     \
