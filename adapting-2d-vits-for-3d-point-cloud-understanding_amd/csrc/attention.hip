@@ -25,6 +25,14 @@
 #define ATT_THREADS 256
 #define HD 64
 #define TILE_BYTES (64 * 128)
+// The tiles are staged with LDS-DMA (global_load_lds), which is tracked by vmcnt, not by the workgroup fence inside
+// __syncthreads(): every wave drains its own DMAs explicitly before the barrier, so that after the barrier all
+// pieces of the tile have landed whatever the wave does next (a wave with no valid row skips the math entirely).
+#define STAGE_FENCE()                          \
+    do {                                       \
+        __builtin_amdgcn_s_waitcnt(0x0F70);    \
+        __syncthreads();                       \
+    } while (0)
 
 struct AttnParams {
     const __bf16* qkv;     // [B*T, 3D]
@@ -36,6 +44,22 @@ struct AttnParams {
     int B, T, H, D;
     float scale;
 };
+
+// Workgroup -> (64-row block, head, sequence).  The hardware deals consecutive workgroups round-robin to the 8 XCDs
+// (each with its own L2); all blocks of one (b,h) re-read the same K/V (or Q/dO) rows, so they are given linear
+// ids that are congruent mod 8 and adjacent in their XCD's queue: the rows cross the fabric once, the other
+// blocks hit that XCD's L2 (measured: -5% on all three kernels at B=256 T=257 H=12).
+__device__ __forceinline__ bool attn_block(const AttnParams& p, int& blk, int& h, int& b) {
+    const int nblk = (p.T + 63) >> 6;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bh = (slot / nblk) * 8 + xcd;
+    blk = slot - (slot / nblk) * nblk;
+    if (bh >= p.B * p.H) return false;
+    b = bh / p.H;
+    h = bh - b * p.H;
+    return true;
+}
+static inline dim3 attn_grid(int B, int T, int H) { return dim3((unsigned)(ceil_div((long long)B * H, 8) * 8 * ceil_div(T, 64))); }
 
 // Stage 64 rows (row r of the tile = global row min(row0 + r, T-1) of sequence b) x 128 B.
 __device__ __forceinline__ void stage_rows(const __bf16* __restrict__ base, size_t ld, int row0, int T,
@@ -98,20 +122,23 @@ template <bool MASK>
 __device__ __forceinline__ void attn_fwd_tile(const char* kt_lds, const char* vt_lds, const bf16x8 (&qf)[2], f32x4 (&o)[4],
                                               float& m, float& lsum, float c, int key0, int T, int lane) {
     const int g = lane >> 4;
+    const int nvalid = MASK ? T - key0 : 64;            // valid keys in this tile (wave-uniform)
     f32x4 s[4];
 #pragma unroll
     for (int k16 = 0; k16 < 4; ++k16) {
         s[k16] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!MASK || k16 * 16 < nvalid) {               // ragged tile: sub-tiles past the end are not computed
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            s[k16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(kt_lds, k16, ks, lane), qf[ks], s[k16], 0, 0, 0);
+            for (int ks = 0; ks < 2; ++ks)
+                s[k16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(kt_lds, k16, ks, lane), qf[ks], s[k16], 0, 0, 0);
+        }
     }
     if (MASK) {
 #pragma unroll
         for (int k16 = 0; k16 < 4; ++k16)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (key0 + k16 * 16 + 4 * g + r >= T) s[k16][r] = -INFINITY;
+                if (k16 * 16 + 4 * g + r >= nvalid) s[k16][r] = -INFINITY;
     }
     float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
@@ -133,16 +160,19 @@ __device__ __forceinline__ void attn_fwd_tile(const char* kt_lds, const char* vt
     for (int d = 0; d < 4; ++d) o[d] *= alpha;
     bf16x8 pb[2] = {pack_pair(s[0], s[1]), pack_pair(s[2], s[3])};
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+    for (int ss = 0; ss < 2; ++ss) {
+        if (MASK && ss * 32 >= nvalid) continue;          // no valid key in this 32-key contraction step
 #pragma unroll
-        for (int ss = 0; ss < 2; ++ss)
+        for (int d = 0; d < 4; ++d)
             o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(vt_lds, ss, d, lane), pb[ss], o[d], 0, 0, 0);
+    }
 }
 
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * TILE_BYTES];     // [buf][K|V]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
-    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int qb, h, b;
+    if (!attn_block(p, qb, h, b)) return;
     const int T = p.T, D = p.D;
     const size_t ld = (size_t)3 * D;
     const __bf16* seq = p.qkv + (size_t)b * T * ld;
@@ -192,16 +222,17 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
     const int nkt = (T + 63) / 64;
     const int nfull = T / 64;                                 // tiles that need no masking
     stage_any(0, lds);
+    const bool wave_active = qb * 64 + wave * 16 < T;     // wave-uniform: a wave with no valid query does no math
     for (int kt = 0; kt < nfull; ++kt) {
-        __syncthreads();
+        STAGE_FENCE();
         const char* cur = lds + (kt & 1) * 2 * TILE_BYTES;
         if (kt + 1 < nkt) stage_any(kt + 1, lds + ((kt + 1) & 1) * 2 * TILE_BYTES);
-        attn_fwd_tile<false>(cur, cur + TILE_BYTES, qf, o, m, lsum, c, kt * 64, T, lane);
+        if (wave_active) attn_fwd_tile<false>(cur, cur + TILE_BYTES, qf, o, m, lsum, c, kt * 64, T, lane);
     }
     if (nfull < nkt) {
-        __syncthreads();
+        STAGE_FENCE();
         const char* cur = lds + (nfull & 1) * 2 * TILE_BYTES;
-        attn_fwd_tile<true>(cur, cur + TILE_BYTES, qf, o, m, lsum, c, nfull * 64, T, lane);
+        if (wave_active) attn_fwd_tile<true>(cur, cur + TILE_BYTES, qf, o, m, lsum, c, nfull * 64, T, lane);
     }
     const float l = xor_lanes_sum(lsum);
     const float inv = 1.0f / l;
@@ -245,7 +276,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const __bf16* __restric
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * TILE_BYTES];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
-    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int qb, h, b;
+    if (!attn_block(p, qb, h, b)) return;
     const int T = p.T, D = p.D;
     const size_t ld = (size_t)3 * D;
     const __bf16* seq = p.qkv + (size_t)b * T * ld;
@@ -263,6 +295,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
     }
     const size_t stat = ((size_t)b * p.H + h) * T + qc;
     const float lse = p.lse2[stat], dl = p.delta[stat];
+    const bool wave_active = qb * 64 + wave * 16 < T;
 
     f32x4 dq[4];
 #pragma unroll
@@ -272,7 +305,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
     stage_rows(kbase, ld, 0, T, lds, wave, lane);
     stage_rows(vbase, ld, 0, T, lds + TILE_BYTES, wave, lane);
     for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();
+        STAGE_FENCE();
         const char* kt_lds = lds + (kt & 1) * 2 * TILE_BYTES;
         const char* vt_lds = kt_lds + TILE_BYTES;
         if (kt + 1 < nkt) {
@@ -280,31 +313,37 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
             stage_rows(kbase, ld, (kt + 1) * 64, T, nxt, wave, lane);
             stage_rows(vbase, ld, (kt + 1) * 64, T, nxt + TILE_BYTES, wave, lane);
         }
+        if (!wave_active) continue;                        // no valid query in this wave: staging + barrier only
+        const bool ragged = kt == nkt - 1 && (T & 63) != 0;
+        const int nvalid = ragged ? T - kt * 64 : 64;     // valid keys in this tile (wave-uniform)
         f32x4 s[4], dp[4];
 #pragma unroll
         for (int k16 = 0; k16 < 4; ++k16) {
             s[k16] = dp[k16] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (k16 * 16 < nvalid) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                s[k16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(kt_lds, k16, ks, lane), qf[ks], s[k16], 0, 0, 0);
-                dp[k16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(vt_lds, k16, ks, lane), dof[ks], dp[k16], 0, 0, 0);
+                for (int ks = 0; ks < 2; ++ks) {
+                    s[k16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(kt_lds, k16, ks, lane), qf[ks], s[k16], 0, 0, 0);
+                    dp[k16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(vt_lds, k16, ks, lane), dof[ks], dp[k16], 0, 0, 0);
+                }
             }
         }
-        const bool ragged = kt == nkt - 1 && (T & 63) != 0;
 #pragma unroll
         for (int k16 = 0; k16 < 4; ++k16)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[k16][r], c, -lse));
-                if (ragged && kt * 64 + k16 * 16 + 4 * g + r >= T) pr = 0.f;
+                if (ragged && k16 * 16 + 4 * g + r >= nvalid) pr = 0.f;
                 s[k16][r] = pr * ((dp[k16][r] - dl) * p.scale);
             }
         bf16x8 db[2] = {pack_pair(s[0], s[1]), pack_pair(s[2], s[3])};
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+        for (int ss = 0; ss < 2; ++ss) {
+            if (ss * 32 >= nvalid) continue;
 #pragma unroll
-            for (int ss = 0; ss < 2; ++ss)
+            for (int d = 0; d < 4; ++d)
                 dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(kt_lds, ss, d, lane), db[ss], dq[d], 0, 0, 0);
+        }
     }
     if (q < T) {
         __bf16* dst = p.out + ((size_t)b * T + q) * ld + h * HD;
@@ -324,7 +363,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[2 * (2 * TILE_BYTES + 512)];   // [buf][Q|dO|lse,delta]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
-    const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int kb, h, b;
+    if (!attn_block(p, kb, h, b)) return;
     const int T = p.T, D = p.D;
     const size_t ld = (size_t)3 * D;
     const __bf16* seq = p.qkv + (size_t)b * T * ld;
@@ -346,6 +386,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv_kernel(AttnParam
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) dk[d] = dv[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool wave_active = kb * 64 + wave * 16 < T;    // wave-uniform: a wave with no valid key does no math
 
     const int nqt = (T + 63) / 64;
     // stats for tile qt live in floats [0,64) = lse2, [64,128) = delta of the buffer
@@ -357,7 +398,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv_kernel(AttnParam
         if (t < 128) reinterpret_cast<float*>(lds + 2 * TILE_BYTES)[t] = stat_next;
     }
     for (int qt = 0; qt < nqt; ++qt) {
-        __syncthreads();
+        STAGE_FENCE();
         const char* cur = lds + (qt & 1) * BUF;
         const char* q_lds = cur;
         const char* do_lds = cur + TILE_BYTES;
@@ -374,17 +415,21 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv_kernel(AttnParam
             stage_rows(dobase, (size_t)D, (qt + 1) * 64, T, nxt + TILE_BYTES, wave, lane);
         }
         f32x4 s[4], dp[4];
+        const bool ragged_q = qt == nqt - 1 && (T & 63) != 0;
+        const int nvalid = ragged_q ? T - qt * 64 : 64;   // valid queries in this tile (wave-uniform)
+        if (wave_active) {
 #pragma unroll
         for (int q16 = 0; q16 < 4; ++q16) {
             s[q16] = dp[q16] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (q16 * 16 < nvalid) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                s[q16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(q_lds, q16, ks, lane), kf[ks], s[q16], 0, 0, 0);
-                dp[q16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(do_lds, q16, ks, lane), vf[ks], dp[q16], 0, 0, 0);
+                for (int ks = 0; ks < 2; ++ks) {
+                    s[q16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(q_lds, q16, ks, lane), kf[ks], s[q16], 0, 0, 0);
+                    dp[q16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(do_lds, q16, ks, lane), vf[ks], dp[q16], 0, 0, 0);
+                }
             }
         }
         f32x4 pr[4];
-        const bool ragged_q = qt == nqt - 1 && (T & 63) != 0;
 #pragma unroll
         for (int q16 = 0; q16 < 4; ++q16) {
             const f32x4 lse4 = *reinterpret_cast<const f32x4*>(st + q16 * 16 + 4 * g);
@@ -392,7 +437,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv_kernel(AttnParam
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[q16][r], c, -lse4[r]));
-                if (ragged_q && qt * 64 + q16 * 16 + 4 * g + r >= T) pv = 0.f;
+                if (ragged_q && q16 * 16 + 4 * g + r >= nvalid) pv = 0.f;
                 pr[q16][r] = pv;
                 s[q16][r] = pv * ((dp[q16][r] - del4[r]) * p.scale);
             }
@@ -400,12 +445,15 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv_kernel(AttnParam
         bf16x8 pb[2] = {pack_pair(pr[0], pr[1]), pack_pair(pr[2], pr[3])};
         bf16x8 db[2] = {pack_pair(s[0], s[1]), pack_pair(s[2], s[3])};
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+        for (int ss = 0; ss < 2; ++ss) {
+            if (ss * 32 >= nvalid) continue;
 #pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {
+            for (int d = 0; d < 4; ++d) {
                 dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(do_lds, ss, d, lane), pb[ss], dv[d], 0, 0, 0);
                 dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(q_lds, ss, d, lane), db[ss], dk[d], 0, 0, 0);
             }
+        }
+        }   // wave_active
         if (more && t < 128) reinterpret_cast<float*>(nxt + 2 * TILE_BYTES)[t] = stat_next;
     }
     if (key < T) {
@@ -423,7 +471,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv_kernel(AttnParam
 static int check_attn(const char* fn, int B, int T, int H, int D) {
     P4P_CHECK(B >= 1 && T >= 1 && H >= 1, "%s: bad sizes B=%d T=%d H=%d", fn, B, T, H);
     P4P_CHECK(D == H * HD, "%s: only head_dim 64 is built (D=%d, H=%d)", fn, D, H);
-    P4P_CHECK(B <= 65535 && H <= 65535, "%s: grid limit", fn);
+    P4P_CHECK((long long)B * H * ceil_div(T, 64) < (1ll << 30), "%s: grid limit", fn);
     return 0;
 }
 
@@ -433,7 +481,7 @@ extern "C" int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B,
     if (check_attn("p4p_attention_fwd", B, T, H, D)) return 1;
     AttnParams p = {};
     p.qkv = (const __bf16*)qkv; p.out = (__bf16*)out; p.lse2 = lse2; p.B = B; p.T = T; p.H = H; p.D = D; p.scale = scale;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(ceil_div(T, 64), H, B), dim3(ATT_THREADS), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(attn_fwd_kernel, attn_grid(B, T, H), dim3(ATT_THREADS), 0, (hipStream_t)stream, p);
     P4P_LAUNCH_CHECK();
     return 0;
 }
@@ -450,7 +498,7 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
     AttnParams p = {};
     p.qkv = (const __bf16*)qkv; p.o = (const __bf16*)o; p.dout = (const __bf16*)dout; p.out = (__bf16*)dqkv;
     p.lse2 = (float*)lse2; p.delta = delta; p.B = B; p.T = T; p.H = H; p.D = D; p.scale = scale;
-    dim3 grid(ceil_div(T, 64), H, B);
+    dim3 grid = attn_grid(B, T, H);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(ATT_THREADS), 0, st, p);
     P4P_LAUNCH_CHECK();
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(ATT_THREADS), 0, st, p);
