@@ -347,11 +347,11 @@ extern "C" int p4p_gemm_wgrad_bf16(const void* G, const void* A, float* dW, floa
         q.out = workspace;
         const bool prof = p4p_prof_begin(1, 2.0 * M * N * K, st);
         if (wgrad3_wide(K) && g_wgrad_wide == 2)
-            hipLaunchKernelGGL((gemm_wgrad3_kernel<256, true>), dim3((N / W3_BN) * (K / 256), splits3), dim3(512), 0, st, q);
+            hipLaunchKernelGGL((gemm_wgrad3_kernel<256, true>), dim3((N / W3_BN) * (K / 256) * splits3), dim3(512), 0, st, q);
         else if (wgrad3_wide(K))
-            hipLaunchKernelGGL(gemm_wgrad3_kernel<256>, dim3((N / W3_BN) * (K / 256), splits3), dim3(512), 0, st, q);
+            hipLaunchKernelGGL(gemm_wgrad3_kernel<256>, dim3((N / W3_BN) * (K / 256) * splits3), dim3(512), 0, st, q);
         else
-            hipLaunchKernelGGL(gemm_wgrad3_kernel<128>, dim3((N / W3_BN) * (K / W3_BK), splits3), dim3(256), 0, st, q);
+            hipLaunchKernelGGL(gemm_wgrad3_kernel<128>, dim3((N / W3_BN) * (K / W3_BK) * splits3), dim3(256), 0, st, q);
         if (prof) p4p_prof_end(st);
         P4P_LAUNCH_CHECK();
         long long n = (long long)N * K;

@@ -36,21 +36,25 @@ enum {
 // Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, i.e. fp32-level; outputs are rounded to bf16 anyway).
 // e = exp(-x^2/2) is shared between Phi and the density term of the derivative.
 __device__ __forceinline__ void phi_and_e(float x, float& Phi, float& e) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    e = __expf(-0.5f * x * x);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float half_tail = 0.5f * poly * e;              // 0.5 * erfc(z)
-    Phi = x >= 0.f ? 1.0f - half_tail : half_tail;
+    // explicit FMAs (the tree is built with -ffp-contract=off for the exact-distance kernels); 0.5 is folded into
+    // the coefficients, the sign select is a copysign (v_bfi)
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(x), 0.3275911f * 0.70710678118654752f, 1.0f));
+    e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170f);                 // exp(-x^2/2)
+    float poly = __builtin_fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+    poly = __builtin_fmaf(t, poly, 0.5f * 1.421413741f);
+    poly = __builtin_fmaf(t, poly, 0.5f * -0.284496736f);
+    poly = __builtin_fmaf(t, poly, 0.5f * 0.254829592f);
+    const float half_tail = (t * poly) * e;               // 0.5 * erfc(|x|/sqrt2)
+    Phi = 0.5f + __builtin_copysignf(0.5f - half_tail, x);
 }
 __device__ __forceinline__ float gelu_f(float x) { float P, e; phi_and_e(x, P, e); return x * P; }
-__device__ __forceinline__ float dgelu_f(float x) { float P, e; phi_and_e(x, P, e); return P + x * 0.3989422804014327f * e; }
+__device__ __forceinline__ float dgelu_f(float x) { float P, e; phi_and_e(x, P, e); return __builtin_fmaf(x * e, 0.3989422804014327f, P); }
 // both at once for the forward epilogue: the backward epilogue then only multiplies by the stored derivative
 __device__ __forceinline__ void gelu_and_dgelu(float x, float& y, float& dy) {
     float P, e;
     phi_and_e(x, P, e);
     y = x * P;
-    dy = P + x * 0.3989422804014327f * e;
+    dy = __builtin_fmaf(x * e, 0.3989422804014327f, P);
 }
 
 // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a

@@ -49,10 +49,17 @@ __global__ __launch_bounds__(BK_ * 2, 2) void gemm_wgrad3_kernel(W3Params p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wn = wave / NWK, wk = wave % NWK;
     const int tiles_k = p.K / BK_;
-    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x - tn * tiles_k;
+    // 1-D grid, split-major work ids, and each XCD owns a contiguous run of ids (xcd_remap): the workgroups that
+    // share an L2 are (almost) all tiles of the SAME M-range, so every G / A row panel crosses the fabric about once
+    // per XCD instead of once per workgroup.  (Measured with the (tile, split) grid, whose tiles of one split are
+    // dealt round-robin to the 8 XCDs: FETCH_SIZE 1.47 GB per launch for 0.4 GB of operands, 6.8 TB/s -- the kernel
+    // ran at the fabric limit, not the MFMA limit.)
+    const int ntiles = (p.N / W3_BN) * tiles_k;
+    const int wid = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = wid / ntiles, tile = wid - split * ntiles;
+    const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
     const int n0 = tn * W3_BN, k0 = tk * BK_;
     (void)APIECES;
-    const int split = blockIdx.y;
     const int total_steps = (p.M + 31) / 32;
     const int step0 = split * p.steps_per_split;
     int nk = total_steps - step0;

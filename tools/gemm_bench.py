@@ -12,7 +12,9 @@ shapes = {'qkv': (M, 3 * D, D, ops.EPI_BF16), 'proj': (M, D, D, ops.EPI_F32_RESI
 variants = [int(v) for v in (sys.argv[1].split(',') if len(sys.argv) > 1 else '1,2,3,11,12,13'.split(','))]
 g = torch.Generator().manual_seed(0)
 res = {}
+only = os.environ.get('GB_SHAPES')
 for name, (m, n, k, epi) in shapes.items():
+    if only and name not in only.split(','): continue
     a = torch.randn(m, k, generator=g).to(torch.bfloat16).to(dev)
     w = (torch.randn(n, k, generator=g) * k ** -0.5).to(torch.bfloat16).to(dev)
     bias = torch.randn(n, generator=g).to(dev)

@@ -25,4 +25,4 @@ for name, (n, k) in shapes.items():
             e.record(); torch.cuda.synchronize()
             res.setdefault(v, []).append(s.elapsed_time(e) / 10 * 1e-3)
     print(name, {v: round(2 * M * n * k / min(t) * 1e-12) for v, t in res.items()}, flush=True)
-lib.p4p_set_wgrad_wide(1)
+lib.p4p_set_wgrad_wide(2)
