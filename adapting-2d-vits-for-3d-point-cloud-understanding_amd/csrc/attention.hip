@@ -41,6 +41,7 @@ struct AttnParams {
     __bf16* out;           // fwd: O [B*T, D]; bwd: dqkv [B*T, 3D]
     float* lse2;           // [B,H,T]
     float* delta;          // [B,H,T]
+    float* colsum;         // bwd, optional: [B*ceil(T/64)*4][3D] per-wave column sums of dqkv (qkv bias gradient)
     int B, T, H, D;
     float scale;
 };
@@ -102,6 +103,35 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* tile, int s, int cb, int l
 __device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
     bf16x8 r = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
     return r;
+}
+
+// Column sums over the wave's 16 rows of an accumulator set held as X^T[col 16d+4g+r][row i] -> 64 floats at dst
+// (global; one partial row per WAVE: no LDS, no barrier -- these kernels are latency-bound per workgroup and two extra
+// barriers in the epilogue cost more than the larger partial buffer).  The qkv bias gradient is the column sum of
+// dqkv; the rows are in registers here, so the backward kernels emit partial sums instead of a separate pass
+// re-reading the 300-MB dqkv.  The bf16-ROUNDED values are summed: the result equals a column sum of the stored
+// tensor up to summation order (which is fixed: reproducible).
+__device__ __forceinline__ void wave_colsum(const f32x4 (&x)[4], bool valid, float* dst, int lane) {
+    // Transposing butterfly over the 16 lanes of a row: at every step a lane keeps the half of its values whose
+    // column-index bit matches its own lane bit and adds the partner's copy of them (xor masks 8, 7, 2, 1 = the DPP
+    // patterns row_ror:8, row_half_mirror, quad_perm[2,3,0,1], quad_perm[1,0,3,2]; they generate all 16 lanes).
+    // 15 DPP adds instead of 64, and lane i ends up with the sum of column c = i (c = 4d + r).
+    const int i = lane & 15, g = lane >> 4;
+    const bool b3 = i & 8, b2 = i & 4, b1 = i & 2, b0 = i & 1;
+    float v[16];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[d * 4 + r] = valid ? bf2f(f2bf(x[d][r])) : 0.f;
+    float w8[8], w4[4], w2[2];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) w8[c] = (b3 ? v[c + 8] : v[c]) + dpp_f32<0x128>(b3 ? v[c] : v[c + 8]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w4[c] = (b2 ? w8[c + 4] : w8[c]) + dpp_f32<0x141>(b2 ? w8[c] : w8[c + 4]);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) w2[c] = (b1 ? w4[c + 2] : w4[c]) + dpp_f32<0x4E>(b1 ? w4[c] : w4[c + 2]);
+    const float tot = (b0 ? w2[1] : w2[0]) + dpp_f32<0xB1>(b0 ? w2[0] : w2[1]);
+    dst[16 * (i >> 2) + 4 * g + (i & 3)] = tot;
 }
 
 __device__ __forceinline__ float xor_lanes_max(float v) {
@@ -345,6 +375,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
                 dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(kt_lds, ss, d, lane), db[ss], dq[d], 0, 0, 0);
         }
     }
+    if (p.colsum) wave_colsum(dq, q < T, p.colsum + (((size_t)b * ((T + 63) >> 6) + qb) * 4 + wave) * ld + h * HD, lane);
     if (q < T) {
         __bf16* dst = p.out + ((size_t)b * T + q) * ld + h * HD;
 #pragma unroll
@@ -456,6 +487,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv_kernel(AttnParam
         }   // wave_active
         if (more && t < 128) reinterpret_cast<float*>(nxt + 2 * TILE_BYTES)[t] = stat_next;
     }
+    if (p.colsum) {
+        float* row = p.colsum + (((size_t)b * ((T + 63) >> 6) + kb) * 4 + wave) * ld + h * HD;
+        wave_colsum(dk, key < T, row + D, lane);
+        wave_colsum(dv, key < T, row + 2 * D, lane);
+    }
     if (key < T) {
         __bf16* dst = p.out + ((size_t)b * T + key) * ld + h * HD;
 #pragma unroll
@@ -487,8 +523,13 @@ extern "C" int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B,
 }
 
 // dqkv receives dq | dk | dv in the layout of qkv.  delta is [B,H,T] workspace.
+extern "C" int p4p_attention_colsum_rows(int B, int T) { return B * ceil_div(T, 64) * 4; }
+
+// colsum_partial (may be null): [p4p_attention_colsum_rows(B,T)][3D] floats; their column sum (p4p_colreduce_f32) is
+// the column sum of dqkv = the gradient of the qkv bias.
 extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse2, float* delta,
-                                 void* dqkv, int B, int T, int H, int D, float scale, void* stream) {
+                                 void* dqkv, float* colsum_partial, int B, int T, int H, int D, float scale,
+                                 void* stream) {
     P4P_CHECK(qkv && o && dout && lse2 && delta && dqkv, "p4p_attention_bwd: null pointer");
     if (check_attn("p4p_attention_bwd", B, T, H, D)) return 1;
     hipStream_t st = (hipStream_t)stream;
@@ -497,7 +538,7 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
     P4P_LAUNCH_CHECK();
     AttnParams p = {};
     p.qkv = (const __bf16*)qkv; p.o = (const __bf16*)o; p.dout = (const __bf16*)dout; p.out = (__bf16*)dqkv;
-    p.lse2 = (float*)lse2; p.delta = delta; p.B = B; p.T = T; p.H = H; p.D = D; p.scale = scale;
+    p.lse2 = (float*)lse2; p.delta = delta; p.colsum = colsum_partial; p.B = B; p.T = T; p.H = H; p.D = D; p.scale = scale;
     dim3 grid = attn_grid(B, T, H);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(ATT_THREADS), 0, st, p);
     P4P_LAUNCH_CHECK();

@@ -152,6 +152,17 @@ extern "C" int p4p_colsum_bf16(const void* G, float* out, float* workspace, int 
     return 0;
 }
 
+// partial[r][N] for r < ceil(M/256) = column sums of rows [256r, 256r+256) of G (bf16); returns through the C ABI so the
+// GEMM launcher (another translation unit) can finish a fused-bias-gradient request on tile shapes without the fusion.
+extern "C" int p4p_colsum_partial_bf16(const void* G, float* partial, int M, int N, void* stream) {
+    P4P_CHECK(G && partial, "p4p_colsum_partial_bf16: null pointer");
+    P4P_CHECK(M >= 1 && N >= 4 && N % 4 == 0, "p4p_colsum_partial_bf16: bad sizes M=%d N=%d", M, N);
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(ceil_div(N, 256), ceil_div(M, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)G, partial, M, N, 256);
+    P4P_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int p4p_token_rows(float* stream_f32, void* compact, int B, int S, int D, int mode, void* stream) {
     P4P_CHECK(stream_f32 && compact && B >= 1 && S >= 1 && D >= 4 && D % 4 == 0 && (mode == 0 || mode == 1),
               "p4p_token_rows: bad arguments");

@@ -43,8 +43,24 @@ static int launch_cfg(const GemmParams& p, hipStream_t st) {
     return 0;
 }
 
+extern "C" int p4p_colsum_partial_bf16(const void* G, float* partial, int M, int N, void* stream);
+
+// EPI_BF16_DGELU with stats: [p4p_gemm_tn_colsum_rows(M)][N] partial column sums of the output (zero rows allowed)
+extern "C" int p4p_gemm_tn_colsum_rows(int M) { return 2 * ceil_div(M, 256); }
+
+template <int EPI>
+static int launch_tn_inner(const GemmParams& p, hipStream_t st);
+
 template <int EPI>
 static int launch_tn(const GemmParams& p, hipStream_t st) {
+    if constexpr (EPI == EPI_BF16_DGELU) {
+        if (p.stats) P4P_HIP(hipMemsetAsync(p.stats, 0, (size_t)p4p_gemm_tn_colsum_rows(p.M) * p.N * sizeof(float), st));
+    }
+    return launch_tn_inner<EPI>(p, st);
+}
+
+template <int EPI>
+static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
     constexpr bool STATS = EPI == EPI_BF16_ROWGROUP || EPI == EPI_BF16_STATS;
     int v = g_gemm_variant;
     if (STATS) v = 1;                         // statistics rows are per 128-row tile (p4p_gemm_tn_stats_rows)
@@ -82,11 +98,12 @@ static int launch_tn(const GemmParams& p, hipStream_t st) {
                 b.out = (char*)p.out + ro * p.N * (EPI == EPI_F32_RESID ? 4 : 2);
                 if (p.resid) b.resid = p.resid + ro * p.N;
                 if (p.pre) b.pre = p.pre + ro * p.N;
+                if (EPI == EPI_BF16_DGELU && p.stats) b.stats = p.stats + (size_t)2 * (a.M / 256) * p.N;   // rows behind the main part's
                 const int saved = g_gemm_variant;
                 g_gemm_variant = v;                                     // main part: no further peeling (rem == 0)
-                int rc = launch_tn<EPI>(a, st);
+                int rc = launch_tn_inner<EPI>(a, st);
                 g_gemm_variant = 6;                                     // 64x64 tiles: 4x more workgroups for the short tail
-                if (!rc) rc = launch_tn<EPI>(b, st);
+                if (!rc) rc = launch_tn_inner<EPI>(b, st);
                 g_gemm_variant = saved;
                 return rc;
             }
@@ -104,6 +121,14 @@ static int launch_tn(const GemmParams& p, hipStream_t st) {
             else hipLaunchKernelGGL((gemm_tn3_kernel<EPI, false, 256>), dim3(tiles), dim3(512), 0, st, p);
             P4P_LAUNCH_CHECK();
             return 0;
+        }
+        if (EPI == EPI_BF16_DGELU && p.stats) {
+            // every other tile configuration: plain launch, then one streaming pass for the column sums
+            GemmParams q = p;
+            q.stats = nullptr;
+            int rc = launch_tn_inner<EPI>(q, st);
+            if (!rc) rc = p4p_colsum_partial_bf16(p.out, p.stats, p.M, p.N, st);
+            return rc;
         }
         if (EPI == EPI_BF16) {     // timing-only ablations of the 256x256 loop (results are wrong by construction)
             if (v == 21) return launch_cfg<256, 256, 2, 4, EPI_BF16, false, 1>(p, st);
@@ -143,6 +168,7 @@ extern "C" int p4p_gemm_tn_bf16(int epi, const void* A, const void* W, void* out
         case EPI_F32_RESID: return launch_tn<EPI_F32_RESID>(p, st);
         case EPI_BF16_DGELU:
             P4P_CHECK(pre, "p4p_gemm_tn_bf16: EPI_BF16_DGELU needs pre");
+            P4P_CHECK(!stats || N % 4 == 0, "p4p_gemm_tn_bf16: column sums need N %% 4 == 0");
             return launch_tn<EPI_BF16_DGELU>(p, st);
         case EPI_BF16_ROWGROUP:
             P4P_CHECK(rowgrp && stats && group >= 1, "p4p_gemm_tn_bf16: EPI_BF16_ROWGROUP needs rowgrp, stats, group");

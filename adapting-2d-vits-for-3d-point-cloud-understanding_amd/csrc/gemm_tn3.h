@@ -276,8 +276,13 @@ __global__ __launch_bounds__(BN_ * 2, 2) void gemm_tn3_kernel(GemmParams p) {
             __syncthreads();
         }
     }
+    // dGELU with p.stats: column sums of the (rounded) output over this wave's 128 rows -> stats[2*tm + wm][n].  Their
+    // column sum is the fc1 bias gradient (autograd of nn.Linear.bias): no separate pass re-reading the 400-MB dh.
+    const bool want_csum = EPI == EPI_BF16_DGELU && p.stats != nullptr;
+    f32x4 csum_all[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+        f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             char* slot = lds + (wm * 128 + j * 16 + li) * CS16 + (wn * 64 + i * 16 + g * 4) * 2;
@@ -288,7 +293,27 @@ __global__ __launch_bounds__(BN_ * 2, 2) void gemm_tn3_kernel(GemmParams p) {
             }
             bf16x4 w = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
             *reinterpret_cast<bf16x4*>(slot) = w;
+            if (EPI == EPI_BF16_DGELU && want_csum && m0 + wm * 128 + j * 16 + li < p.M)
+                csum += f32x4{bf2f(w[0]), bf2f(w[1]), bf2f(w[2]), bf2f(w[3])};
         }
+        if (EPI == EPI_BF16_DGELU && want_csum) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                  // sum over the 16 rows li of this 16-lane group
+                float v = csum[r];
+                v += dpp_f32<0xB1>(v);
+                v += dpp_f32<0x4E>(v);
+                v += dpp_f32<0x141>(v);
+                v += dpp_f32<0x140>(v);
+                csum[r] = v;
+            }
+        }
+        csum_all[i] = csum;
+    }
     __syncthreads();
     copy_out((__bf16*)p.out);
+    if (EPI == EPI_BF16_DGELU && want_csum && li == 0) {     // after the barrier: it would wait for these stores' acks
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<f32x4*>(p.stats + (size_t)(tm * 2 + wm) * p.N + n0 + wn * 64 + i * 16 + g * 4) = csum_all[i];
+    }
 }

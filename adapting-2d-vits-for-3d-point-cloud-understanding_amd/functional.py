@@ -7,6 +7,8 @@
 Forward and backward both run hand-written kernels; torch is only the allocator, the stream and
 the autograd graph.  Saved activations are bf16 except the fp32 residual stream.
 """
+import os
+
 import torch
 
 from . import ops
@@ -144,6 +146,9 @@ def linear(x, weight, bias):
 # ViT encoder: L blocks + final norm
 # ================================================================================================
 _BLOCK_PARAMS = 12     # n1w n1b qkvw qkvb projw projb n2w n2b fc1w fc1b fc2w fc2b
+# bias gradients of qkv / fc1 from inside the kernels that produce dqkv / dh (A/B switches for tools/, default on)
+_FUSE_QKV_BIAS = os.environ.get('P4P_FUSE_QKV_BIAS', '0') != '0'   # measured: no gain (attention bwd is VALU-bound)
+_FUSE_FC1_BIAS = os.environ.get('P4P_FUSE_FC1_BIAS', '1') != '0'
 
 
 def block_params(blk):
@@ -214,12 +219,18 @@ class _EncoderFn(torch.autograd.Function):
             wg = need[8 + l * _BLOCK_PARAMS + 2]       # block weights trainable? (frozen ViT => False)
             # ---- mlp: x = x1 + fc2(gelu(fc1(ln2)))
             _, Wfc2T = _bf16_weights(fc2w, True)
-            dh = ops.gemm_tn(dxb, Wfc2T, ops.EPI_BF16_DGELU, pre=hpre)
+            if wg and _FUSE_FC1_BIAS:        # fc1 bias gradient = column sums of dh, accumulated in the same epilogue
+                dh, dfc1b = ops.gemm_tn(dxb, Wfc2T, ops.EPI_BF16_DGELU, pre=hpre, want_colsum=True)
+            else:
+                dh = ops.gemm_tn(dxb, Wfc2T, ops.EPI_BF16_DGELU, pre=hpre)
             _, Wfc1T = _bf16_weights(fc1w, True)
             dln2 = ops.gemm_tn(dh, Wfc1T, ops.EPI_BF16)
             if wg:
                 dfc2w, dfc2b = ops.gemm_wgrad(dxb, g), dx_colsum
-                dfc1w, dfc1b = ops.gemm_wgrad(dh, ln2, want_bias=True)
+                if _FUSE_FC1_BIAS:
+                    dfc1w = ops.gemm_wgrad(dh, ln2)
+                else:
+                    dfc1w, dfc1b = ops.gemm_wgrad(dh, ln2, want_bias=True)
             del dh
             _, dn2w, dn2b, dx_colsum = ops.layernorm_bwd(dln2, x1, mean2, rstd2, n2w.detach(), dx=dx, dx_bf16=dxb,
                                                          want_dxsum=True)
@@ -228,11 +239,17 @@ class _EncoderFn(torch.autograd.Function):
             datt = ops.gemm_tn(dxb, WprojT, ops.EPI_BF16)
             if wg:
                 dprojw, dprojb = ops.gemm_wgrad(dxb, att), dx_colsum
-            dqkv = ops.attention_bwd(qkv, att, datt, lse, B, T, H)
+            if wg and _FUSE_QKV_BIAS:
+                dqkv, dqkvb = ops.attention_bwd(qkv, att, datt, lse, B, T, H, want_colsum=True)
+            else:
+                dqkv = ops.attention_bwd(qkv, att, datt, lse, B, T, H)
             _, WqkvT = _bf16_weights(qkvw, True)
             dln1 = ops.gemm_tn(dqkv, WqkvT, ops.EPI_BF16)
             if wg:
-                dqkvw, dqkvb = ops.gemm_wgrad(dqkv, ln1, want_bias=True)
+                if _FUSE_QKV_BIAS:
+                    dqkvw = ops.gemm_wgrad(dqkv, ln1)
+                else:
+                    dqkvw, dqkvb = ops.gemm_wgrad(dqkv, ln1, want_bias=True)
             del dqkv, datt
             _, dn1w, dn1b, dx_colsum = ops.layernorm_bwd(dln1, xin, mean1, rstd1, n1w.detach(), dx=dx, dx_bf16=dxb,
                                                          dacc=dpos, dacc_init=(l == L - 1), want_dxsum=True)

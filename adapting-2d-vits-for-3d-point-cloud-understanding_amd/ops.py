@@ -70,8 +70,9 @@ def group_gather(src, idx):
 
 # ---------------------------------------------------------------- GEMMs
 def gemm_tn(a, w, epilogue=EPI_BF16, bias=None, resid=None, pre=None, rowgrp=None, group=1, out=None,
-            want_stats=False, want_pre=False):
-    """out[M,N] = a[M,K] @ w[N,K]^T with a fused epilogue (see include/p4p_hip.h)."""
+            want_stats=False, want_pre=False, want_colsum=False):
+    """out[M,N] = a[M,K] @ w[N,K]^T with a fused epilogue (see include/p4p_hip.h).  want_colsum (EPI_BF16_DGELU
+    only) also returns the column sums of out = the bias gradient of the Linear that produced `pre`."""
     _chk(a, 'a', torch.bfloat16, 2)
     _chk(w, 'w', torch.bfloat16, 2)
     M, K = a.shape
@@ -87,12 +88,20 @@ def gemm_tn(a, w, epilogue=EPI_BF16, bias=None, resid=None, pre=None, rowgrp=Non
         stats = torch.empty(rows, 2, N, dtype=torch.float32, device=a.device)
     if epilogue == EPI_BF16_GELU and want_pre and pre is None:
         pre = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    cs_rows = 0
+    if want_colsum:
+        if epilogue != EPI_BF16_DGELU:
+            raise RuntimeError('gemm_tn: want_colsum is only built for EPI_BF16_DGELU')
+        cs_rows = L.call_int('p4p_gemm_tn_colsum_rows', M)
+        stats = _workspace('dgelu_colsum', cs_rows * N, a.device)
     for t, nm, dt in ((bias, 'bias', torch.float32), (resid, 'resid', torch.float32),
                       (pre, 'pre', torch.bfloat16), (rowgrp, 'rowgrp', torch.float32)):
         if t is not None:
             _chk(t, nm, dt)
     L.call('p4p_gemm_tn_bf16', int(epilogue), L.ptr(a), L.ptr(w), L.ptr(out), L.ptr(bias), L.ptr(resid),
            L.ptr(pre), L.ptr(rowgrp), L.ptr(stats), M, N, K, int(group), _stream())
+    if want_colsum:
+        return out, colreduce(stats, cs_rows, N)
     if stats is not None:
         return out, stats
     if epilogue == EPI_BF16_GELU and want_pre:
@@ -189,7 +198,9 @@ def attention_fwd(qkv, B, T, H, want_lse=True):
     return out, lse
 
 
-def attention_bwd(qkv, o, dout, lse, B, T, H):
+def attention_bwd(qkv, o, dout, lse, B, T, H, want_colsum=False):
+    """dqkv; with want_colsum also the column sums of dqkv (the qkv bias gradient), accumulated per 64-row block
+    inside the backward kernels and reduced here (no extra pass over dqkv)."""
     _chk(qkv, 'qkv', torch.bfloat16, 2)
     _chk(o, 'o', torch.bfloat16, 2)
     _chk(dout, 'dout', torch.bfloat16, 2)
@@ -197,8 +208,14 @@ def attention_bwd(qkv, o, dout, lse, B, T, H):
     D = o.shape[1]
     dqkv = torch.empty_like(qkv)
     delta = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
-    L.call('p4p_attention_bwd', L.ptr(qkv), L.ptr(o), L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dqkv), B, T, H, D,
-           float((D // H) ** -0.5), _stream())
+    part = None
+    if want_colsum:
+        rows = L.call_int('p4p_attention_colsum_rows', B, T)
+        part = _workspace('attn_colsum', rows * 3 * D, qkv.device)
+    L.call('p4p_attention_bwd', L.ptr(qkv), L.ptr(o), L.ptr(dout), L.ptr(lse), L.ptr(delta), L.ptr(dqkv), L.ptr(part),
+           B, T, H, D, float((D // H) ** -0.5), _stream())
+    if want_colsum:
+        return dqkv, colreduce(part, rows, 3 * D)
     return dqkv
 
 

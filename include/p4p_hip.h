@@ -53,6 +53,10 @@ enum p4p_epilogue {
 int p4p_gemm_tn_bf16(int epilogue, const void* A, const void* W, void* out, const float* bias, const float* resid,
                      void* pre, const float* rowgrp, float* stats, int M, int N, int K, int group, void* stream);
 int p4p_gemm_tn_stats_rows(int M);
+/* EPI_BF16_DGELU accepts stats = [p4p_gemm_tn_colsum_rows(M)][N] f32: partial column sums of the output written by the
+   same epilogue (zero rows allowed); reduced with p4p_colreduce_f32 they are the bias gradient of the Linear that
+   produced `pre` (autograd of timm Mlp.fc1.bias). */
+int p4p_gemm_tn_colsum_rows(int M);
 
 /* dW[N,K] (f32) = beta*dW + G[M,N]^T A[M,K]  (autograd of nn.Linear.weight).  N,K % 8 == 0.
  * dbias[N] (may be NULL) = beta*dbias + column sums of G (autograd of nn.Linear.bias), from the same pass.
@@ -84,9 +88,12 @@ int p4p_colreduce_f32(const float* part, float* out, int nrows, long long stride
 
 /* qkv [B*T,3D] bf16 (q|k|v, heads inside), out [B*T,D] bf16, lse2 [B,H,T] f32 (may be NULL for inference). */
 int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B, int T, int H, int D, float scale, void* stream);
-/* dqkv [B*T,3D] bf16 <- gradients; delta [B,H,T] f32 workspace. */
+/* dqkv [B*T,3D] bf16 <- gradients; delta [B,H,T] f32 workspace.  colsum_partial (may be NULL):
+   [p4p_attention_colsum_rows(B,T)][3D] f32 per-wave column sums of dqkv, written by the same kernels; reduced with
+   p4p_colreduce_f32 they are the gradient of the qkv bias (autograd of nn.Linear.bias in timm Attention.qkv). */
 int p4p_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse2, float* delta, void* dqkv,
-                      int B, int T, int H, int D, float scale, void* stream);
+                      float* colsum_partial, int B, int T, int H, int D, float scale, void* stream);
+int p4p_attention_colsum_rows(int B, int T);
 
 /* ---- streaming helpers ----------------------------------------------------------------------------- */
 
@@ -96,6 +103,8 @@ int p4p_cast_f32_bf16(const float* src, void* dst, long long n, void* stream);
 /* out[N] = beta*out + column sums of G[M,N] bf16 (autograd of nn.Linear.bias). workspace: p4p_colsum_splits(M)*N f32 */
 int p4p_colsum_bf16(const void* G, float* out, float* workspace, int M, int N, float beta, void* stream);
 int p4p_colsum_splits(int M);
+/* partial[r][N] f32, r < ceil(M/256): column sums of rows [256r, 256r+256) of G[M,N] bf16 (no final reduction). */
+int p4p_colsum_partial_bf16(const void* G, float* partial, int M, int N, void* stream);
 /* token stream [B,T=S+1,D] f32 <-> compact patch rows [B*S,D] (cls row first, pix4point.py:248-252).
  * mode 0: compact(bf16) = stream rows; mode 1: stream rows = compact(f32). */
 int p4p_token_rows(float* stream_f32, void* compact, int B, int S, int D, int mode, void* stream);

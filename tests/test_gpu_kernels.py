@@ -202,6 +202,27 @@ def test_gemm_tn_epilogues_random():
     torch.testing.assert_close(st.sum(0)[0], ref.sum(0), rtol=1e-4, atol=1e-2)
 
 
+@pytest.mark.parametrize('variant', [0, 1, 3, 4, 6, 8])
+@pytest.mark.parametrize('M,N,K', [(777, 512, 256), (66 * 256, 768, 256), (2049, 256, 128)])
+def test_gemm_tn_dgelu_fused_bias_gradient(M, N, K, variant):
+    """EPI_BF16_DGELU with want_colsum: the column sums of the stored (bf16) output, from the GEMM epilogue on the ring
+    kernels (incl. the peeled tail of the 66-panel case) and from the streaming fallback on the other tile shapes."""
+    g = torch.Generator().manual_seed(M + variant)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(DEV)
+    pre = torch.rand(M, N, generator=g).to(torch.bfloat16).to(DEV)
+    from p4p_amd import _lib
+    old = _lib.lib().p4p_set_gemm_variant(variant)
+    try:
+        plain = ops.gemm_tn(a, w, ops.EPI_BF16_DGELU, pre=pre)
+        out, cs = ops.gemm_tn(a, w, ops.EPI_BF16_DGELU, pre=pre, want_colsum=True)
+    finally:
+        _lib.lib().p4p_set_gemm_variant(old)
+    assert torch.equal(out, plain)
+    want = out.double().sum(0)
+    assert (cs.double() - want).abs().max().item() <= 1e-5 * max(out.float().abs().sum(0).max().item(), 1.0)
+
+
 @pytest.mark.parametrize('M,N,K', [(64, 128, 128), (200, 256, 192), (2056, 576, 192), (4099, 192, 768), (1000, 8, 64)])
 def test_gemm_wgrad_exact_on_integer_data(M, N, K):
     g = _int_bf16((M, N), -1, 1, 3).to(DEV)
@@ -270,6 +291,11 @@ def test_attention_fwd_bwd(B, T, H):
     err = (dqkv.float() - qr.grad).abs().max().item()
     scale = qr.grad.abs().max().item()
     assert err <= 3e-2 * max(scale, 1.0), (err, scale)
+    # fused qkv-bias gradient: per-block column sums of the (rounded) dqkv from inside the backward kernels
+    dqkv2, dbias = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
+    assert torch.equal(dqkv2, dqkv)
+    want = dqkv.double().sum(0)
+    assert (dbias.double() - want).abs().max().item() <= 1e-5 * max(dqkv.float().abs().sum(0).max().item(), 1.0)
     # forces the online-softmax rescale: one key dominates late in the sequence
     if T >= 65:
         spike = qkv.clone().view(B, T, 3, H, 64)
