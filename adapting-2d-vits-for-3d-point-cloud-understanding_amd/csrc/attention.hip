@@ -303,6 +303,43 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const __bf16* __restric
 // dQ: same decomposition as forward (query on the lane), K/V tiles stream.
 //   dP^T[key][q] = V . dO^T ;  dS^T = p * (dP^T - delta[q]) * scale ;  dQ^T[d][q] += K^T . dS^T
 // ------------------------------------------------------------------------------------------------
+// One K/V tile of the dQ pass for a wave's 16 queries.  RAGGED (compile time) is the last tile when T % 64 != 0: only
+// it pays for the key masks and the sub-tile skips.  dS is left unscaled; the kernel applies `scale` to dQ once.
+template <bool RAGGED>
+__device__ __forceinline__ void attn_dq_tile(const char* kt_lds, const char* vt_lds, const bf16x8 (&qf)[2],
+                                             const bf16x8 (&dof)[2], f32x4 (&dq)[4], float c, float lse, float dl,
+                                             int nvalid, int lane) {
+    const int g = lane >> 4;
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int k16 = 0; k16 < 4; ++k16) {
+        s[k16] = dp[k16] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!RAGGED || k16 * 16 < nvalid) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                s[k16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(kt_lds, k16, ks, lane), qf[ks], s[k16], 0, 0, 0);
+                dp[k16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(vt_lds, k16, ks, lane), dof[ks], dp[k16], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int k16 = 0; k16 < 4; ++k16)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[k16][r], c, -lse));
+            if (RAGGED && k16 * 16 + 4 * g + r >= nvalid) pr = 0.f;
+            s[k16][r] = pr * (dp[k16][r] - dl);
+        }
+    bf16x8 db[2] = {pack_pair(s[0], s[1]), pack_pair(s[2], s[3])};
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+        if (RAGGED && ss * 32 >= nvalid) continue;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(kt_lds, ss, d, lane), db[ss], dq[d], 0, 0, 0);
+    }
+}
+
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * TILE_BYTES];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
@@ -331,7 +368,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
 #pragma unroll
     for (int d = 0; d < 4; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nkt = (T + 63) / 64;
+    const int nkt = (T + 63) / 64, nfull = T / 64;
     stage_rows(kbase, ld, 0, T, lds, wave, lane);
     stage_rows(vbase, ld, 0, T, lds + TILE_BYTES, wave, lane);
     for (int kt = 0; kt < nkt; ++kt) {
@@ -344,37 +381,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
             stage_rows(vbase, ld, (kt + 1) * 64, T, nxt + TILE_BYTES, wave, lane);
         }
         if (!wave_active) continue;                        // no valid query in this wave: staging + barrier only
-        const bool ragged = kt == nkt - 1 && (T & 63) != 0;
-        const int nvalid = ragged ? T - kt * 64 : 64;     // valid keys in this tile (wave-uniform)
-        f32x4 s[4], dp[4];
-#pragma unroll
-        for (int k16 = 0; k16 < 4; ++k16) {
-            s[k16] = dp[k16] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (k16 * 16 < nvalid) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    s[k16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(kt_lds, k16, ks, lane), qf[ks], s[k16], 0, 0, 0);
-                    dp[k16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(vt_lds, k16, ks, lane), dof[ks], dp[k16], 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int k16 = 0; k16 < 4; ++k16)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[k16][r], c, -lse));
-                if (ragged && k16 * 16 + 4 * g + r >= nvalid) pr = 0.f;
-                s[k16][r] = pr * ((dp[k16][r] - dl) * p.scale);
-            }
-        bf16x8 db[2] = {pack_pair(s[0], s[1]), pack_pair(s[2], s[3])};
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-            if (ss * 32 >= nvalid) continue;
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-                dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(kt_lds, ss, d, lane), db[ss], dq[d], 0, 0, 0);
-        }
+        if (kt < nfull) attn_dq_tile<false>(kt_lds, vt_lds, qf, dof, dq, c, lse, dl, 64, lane);
+        else attn_dq_tile<true>(kt_lds, vt_lds, qf, dof, dq, c, lse, dl, T - kt * 64, lane);
     }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) dq[d] *= p.scale;
     if (p.colsum) wave_colsum(dq, q < T, p.colsum + (((size_t)b * ((T + 63) >> 6) + qb) * 4 + wave) * ld + h * HD, lane);
     if (q < T) {
         __bf16* dst = p.out + ((size_t)b * T + q) * ld + h * HD;
@@ -391,6 +402,50 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
 //   S[q][key] = Q . K^T ; dP[q][key] = dO . V^T ; P = exp2(c S - lse2[q]) ; dS = P (dP - delta[q]) scale
 //   dV^T[d][key] += dO^T . P ;  dK^T[d][key] += Q^T . dS
 // ------------------------------------------------------------------------------------------------
+// One Q/dO tile of the dK/dV pass for a wave's 16 keys (RAGGED as in attn_dq_tile; dS unscaled, `scale` goes on dK once).
+template <bool RAGGED>
+__device__ __forceinline__ void attn_dkdv_tile(const char* q_lds, const char* do_lds, const float* st, const bf16x8 (&kf)[2],
+                                               const bf16x8 (&vf)[2], f32x4 (&dk)[4], f32x4 (&dv)[4], float c, int nvalid,
+                                               int lane) {
+    const int g = lane >> 4;
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int q16 = 0; q16 < 4; ++q16) {
+        s[q16] = dp[q16] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!RAGGED || q16 * 16 < nvalid) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                s[q16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(q_lds, q16, ks, lane), kf[ks], s[q16], 0, 0, 0);
+                dp[q16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(do_lds, q16, ks, lane), vf[ks], dp[q16], 0, 0, 0);
+            }
+        }
+    }
+    f32x4 pr[4];
+#pragma unroll
+    for (int q16 = 0; q16 < 4; ++q16) {
+        const f32x4 lse4 = *reinterpret_cast<const f32x4*>(st + q16 * 16 + 4 * g);
+        const f32x4 del4 = *reinterpret_cast<const f32x4*>(st + 64 + q16 * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[q16][r], c, -lse4[r]));
+            if (RAGGED && q16 * 16 + 4 * g + r >= nvalid) pv = 0.f;
+            pr[q16][r] = pv;
+            s[q16][r] = pv * (dp[q16][r] - del4[r]);
+        }
+    }
+    bf16x8 pb[2] = {pack_pair(pr[0], pr[1]), pack_pair(pr[2], pr[3])};
+    bf16x8 db[2] = {pack_pair(s[0], s[1]), pack_pair(s[2], s[3])};
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+        if (RAGGED && ss * 32 >= nvalid) continue;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(do_lds, ss, d, lane), pb[ss], dv[d], 0, 0, 0);
+            dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(q_lds, ss, d, lane), db[ss], dk[d], 0, 0, 0);
+        }
+    }
+}
+
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[2 * (2 * TILE_BYTES + 512)];   // [buf][Q|dO|lse,delta]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
@@ -445,48 +500,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv_kernel(AttnParam
             stage_rows(qbase, ld, (qt + 1) * 64, T, nxt, wave, lane);
             stage_rows(dobase, (size_t)D, (qt + 1) * 64, T, nxt + TILE_BYTES, wave, lane);
         }
-        f32x4 s[4], dp[4];
-        const bool ragged_q = qt == nqt - 1 && (T & 63) != 0;
-        const int nvalid = ragged_q ? T - qt * 64 : 64;   // valid queries in this tile (wave-uniform)
         if (wave_active) {
-#pragma unroll
-        for (int q16 = 0; q16 < 4; ++q16) {
-            s[q16] = dp[q16] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (q16 * 16 < nvalid) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    s[q16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(q_lds, q16, ks, lane), kf[ks], s[q16], 0, 0, 0);
-                    dp[q16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(do_lds, q16, ks, lane), vf[ks], dp[q16], 0, 0, 0);
-                }
-            }
+            if ((qt + 1) * 64 <= T) attn_dkdv_tile<false>(q_lds, do_lds, st, kf, vf, dk, dv, c, 64, lane);
+            else attn_dkdv_tile<true>(q_lds, do_lds, st, kf, vf, dk, dv, c, T - qt * 64, lane);
         }
-        f32x4 pr[4];
-#pragma unroll
-        for (int q16 = 0; q16 < 4; ++q16) {
-            const f32x4 lse4 = *reinterpret_cast<const f32x4*>(st + q16 * 16 + 4 * g);
-            const f32x4 del4 = *reinterpret_cast<const f32x4*>(st + 64 + q16 * 16 + 4 * g);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[q16][r], c, -lse4[r]));
-                if (ragged_q && q16 * 16 + 4 * g + r >= nvalid) pv = 0.f;
-                pr[q16][r] = pv;
-                s[q16][r] = pv * ((dp[q16][r] - del4[r]) * p.scale);
-            }
-        }
-        bf16x8 pb[2] = {pack_pair(pr[0], pr[1]), pack_pair(pr[2], pr[3])};
-        bf16x8 db[2] = {pack_pair(s[0], s[1]), pack_pair(s[2], s[3])};
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-            if (ss * 32 >= nvalid) continue;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(do_lds, ss, d, lane), pb[ss], dv[d], 0, 0, 0);
-                dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(q_lds, ss, d, lane), db[ss], dk[d], 0, 0, 0);
-            }
-        }
-        }   // wave_active
         if (more && t < 128) reinterpret_cast<float*>(nxt + 2 * TILE_BYTES)[t] = stat_next;
     }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) dk[d] *= p.scale;
     if (p.colsum) {
         float* row = p.colsum + (((size_t)b * ((T + 63) >> 6) + kb) * 4 + wave) * ld + h * HD;
         wave_colsum(dk, key < T, row + D, lane);
