@@ -105,11 +105,20 @@ void gemm_tn2_kernel(GemmParams p) {
             __builtin_amdgcn_global_load_lds(GLB_PTR(src[q] + kt * 64), LDS_PTR(buf + (wave * PPW + q) * 1024), 16, 0, 0);
     };
 
+    // EPI_BF16_ROWGROUP: the per-group addend is the INITIAL value of the accumulators -- its loads are issued here,
+    // next to the first operand stages, instead of as a dependent global read in the epilogue (K is short on this path:
+    // the tokenizer's 1x1 convs; the epilogue latency chain was most of the tile time)
     f32x4 acc[NTL][MT];
 #pragma unroll
     for (int i = 0; i < NTL; ++i)
 #pragma unroll
-        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MT; ++j) {
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (EPI == EPI_BF16_ROWGROUP) {
+                const int m = m0 + wm * WM_ + j * 16 + (lane & 15), n = n0 + wn * WN_ + i * 16 + (lane >> 4) * 4;
+                if (m < p.M && n < p.N) acc[i][j] = *reinterpret_cast<const f32x4*>(p.rowgrp + (size_t)(m / p.group) * p.N + n);
+            }
+        }
 
     const int frag_off = (lane & 15) * 128 + ((((lane >> 4)) ^ (lane & 7)) << 4);
     const int a_base = wm * WM_ * 128 + frag_off;
@@ -223,8 +232,6 @@ void gemm_tn2_kernel(GemmParams p) {
                     bf16x4 h = *reinterpret_cast<const bf16x4*>(p.pre + o);
                     v = f32x4{v[0] * bf2f(h[0]), v[1] * bf2f(h[1]), v[2] * bf2f(h[2]), v[3] * bf2f(h[3])};
                 }
-            } else if (EPI == EPI_BF16_ROWGROUP) {
-                if (ok) v += *reinterpret_cast<const f32x4*>(p.rowgrp + (size_t)(m / p.group) * p.N + n);
             }
             if (STATS && ok) {
 #pragma unroll
@@ -233,6 +240,26 @@ void gemm_tn2_kernel(GemmParams p) {
             bf16x4 w = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
             *reinterpret_cast<bf16x4*>(lds + ml * CSTRIDE + nl * 2) = w;
         }
+    }
+    // column statistics: 16 rows held across the lanes of one DPP row -> reduce, park per wave-row in LDS BEHIND the
+    // staging tile; the same barrier publishes both, and the final sums leave together with the output stores (a
+    // barrier after the stores would wait for their acknowledgement: ~2 us per tile on this short-K path)
+    float* red = reinterpret_cast<float*>(lds + BM_ * CSTRIDE);       // [WAVES_M][2][BN]
+    static_assert(!STATS || BM_ * CSTRIDE + WAVES_M * 2 * BN_ * 4 <= 2 * STAGE, "statistics must fit behind the staging tile");
+    if (STATS) {
+#pragma unroll
+        for (int i = 0; i < NTL; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = csum[i][r], b = csq[i][r];
+                a += dpp_f32<0xB1>(a); a += dpp_f32<0x4E>(a); a += dpp_f32<0x141>(a); a += dpp_f32<0x140>(a);
+                b += dpp_f32<0xB1>(b); b += dpp_f32<0x4E>(b); b += dpp_f32<0x141>(b); b += dpp_f32<0x140>(b);
+                if (li == 0) {
+                    const int c = wn * WN_ + i * 16 + g * 4 + r;
+                    red[(wm * 2 + 0) * BN_ + c] = a;
+                    red[(wm * 2 + 1) * BN_ + c] = b;
+                }
+            }
     }
     if (BF16_OUT) {
         __syncthreads();
@@ -247,23 +274,6 @@ void gemm_tn2_kernel(GemmParams p) {
         }
     }
     if (STATS) {
-        // 16 rows held across lanes of one DPP row -> reduce, then the WAVES_M row-waves through LDS
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(lds);           // [WAVES_M][2][BN]
-#pragma unroll
-        for (int i = 0; i < NTL; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float a = csum[i][r], b = csq[i][r];
-                a += dpp_f32<0xB1>(a); a += dpp_f32<0x4E>(a); a += dpp_f32<0x141>(a); a += dpp_f32<0x140>(a);
-                b += dpp_f32<0xB1>(b); b += dpp_f32<0x4E>(b); b += dpp_f32<0x141>(b); b += dpp_f32<0x140>(b);
-                if (li == 0) {
-                    const int c = wn * WN_ + i * 16 + g * 4 + r;
-                    red[(wm * 2 + 0) * BN_ + c] = a;
-                    red[(wm * 2 + 1) * BN_ + c] = b;
-                }
-            }
-        __syncthreads();
         for (int c = t; c < BN_; c += NT_) {
             if (n0 + c < p.N) {
                 float a = 0.f, b = 0.f;
