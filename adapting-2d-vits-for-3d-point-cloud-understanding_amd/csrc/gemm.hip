@@ -75,7 +75,9 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
         // with the hand-interleaved issue order {LDS-DMA, 4 MFMA, 3 reads, 4 MFMA} (8) wins for every fused epilogue
         // (proj 438 vs 380, fc2 852 vs 782, dfc2 691 vs 671, fc1 586 vs 569) and for long K (dfc1 1052 vs 1018);
         // the mid-tile-barrier schedule (3) keeps the plain bf16 epilogue at K = 768 (qkv 911 vs 884)
-        if (big256) v = (EPI == EPI_BF16 && p.K < 1536) ? 3 : 8;
+        // (with the per-wave streamed epilogue of gemm_tn3.h the ring kernel also wins the plain bf16 epilogue at
+        //  K = 768: qkv 921 vs 882 for the mid-tile-barrier kernel, whose epilogue still runs as workgroup phases)
+        if (big256) v = 8;
         else if (p.N % T3_BN == 0 && big) v = 4;
         else v = 1;
     }
