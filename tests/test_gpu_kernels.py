@@ -168,6 +168,37 @@ def test_gemm_tn_exact_on_integer_data(M, N, K):
     assert torch.equal(got32, 2 * want + bias)
 
 
+@pytest.mark.parametrize('variant', [3, 4, 8])
+@pytest.mark.parametrize('M', [300 * 256, 300 * 256 - 100])
+def test_gemm_tn_big_tile_kernels_exact_on_integer_data(M, variant):
+    """The 256-row tile kernels (mid-tile-barrier, 256x128 ring, 256x256 ring) on a grid of 600 tiles
+    (with a ragged last panel): exact against fp32 on integer operands, and the
+    GELU / dGELU epilogues bit-identical to the 128x128 kernel's."""
+    from p4p_amd import _lib
+    N, K = 512, 128
+    a = _int_bf16((M, K), -2, 2, 11).to(DEV)
+    w = _int_bf16((N, K), -1, 1, 12).to(DEV)
+    want = a.float() @ w.float().t()
+    bias = torch.arange(N, device=DEV, dtype=torch.float32) % 5 - 2
+    pre = (torch.arange(M * N, device=DEV) % 7 - 3).to(torch.bfloat16).view(M, N)
+    lib = _lib.lib()
+    old = lib.p4p_set_gemm_variant(1)
+    try:
+        ref_gelu, ref_pre = ops.gemm_tn(a, w, ops.EPI_BF16_GELU, bias=bias, want_pre=True)
+        ref_dgelu = ops.gemm_tn(a, w, ops.EPI_BF16_DGELU, pre=pre)
+        lib.p4p_set_gemm_variant(variant)
+        got = ops.gemm_tn(a, w, ops.EPI_BF16)
+        got32 = ops.gemm_tn(a, w, ops.EPI_F32_RESID, bias=bias, resid=want.clone())
+        gelu, gpre = ops.gemm_tn(a, w, ops.EPI_BF16_GELU, bias=bias, want_pre=True)
+        dgelu = ops.gemm_tn(a, w, ops.EPI_BF16_DGELU, pre=pre)
+    finally:
+        lib.p4p_set_gemm_variant(old)
+    assert torch.equal(got.float(), want)
+    assert torch.equal(got32, 2 * want + bias)
+    assert torch.equal(gelu, ref_gelu) and torch.equal(gpre, ref_pre)
+    assert torch.equal(dgelu, ref_dgelu)
+
+
 def test_gemm_tn_epilogues_random():
     M, N, K = 777, 320, 256
     g = torch.Generator().manual_seed(0)
@@ -203,7 +234,7 @@ def test_gemm_tn_epilogues_random():
 
 
 @pytest.mark.parametrize('variant', [0, 1, 3, 4, 6, 8])
-@pytest.mark.parametrize('M,N,K', [(777, 512, 256), (66 * 256, 768, 256), (2049, 256, 128)])
+@pytest.mark.parametrize('M,N,K', [(777, 512, 256), (66 * 256, 768, 256), (2049, 256, 128), (300 * 256, 512, 128)])
 def test_gemm_tn_dgelu_fused_bias_gradient(M, N, K, variant):
     """EPI_BF16_DGELU with want_colsum: the column sums of the stored (bf16) output, from the GEMM epilogue on the ring
     kernels (incl. the peeled tail of the 66-panel case) and from the streaming fallback on the other tile shapes."""
