@@ -119,9 +119,19 @@ def instrumented_roofline(stepper, batch, steps):
     agg_ms = sum(r['ms'] for r in res.values())
     dom = max(res.values(), key=lambda r: r['ms'] if r['name'].startswith('gemm_wgrad3') else 0)
     ach = dom['flops'] / (dom['ms'] * 1e-3) * 1e-12
+    # HBM-side bytes per launch of the same kernel: PMC counters need rocprofv3 around the process, so the figure is
+    # the committed measurement of this command (profiles/r01_pmc_wgrad.json: FETCH_SIZE x2 + WRITE_SIZE, separate
+    # passes, as MI355X_MICROARCH.md prescribes); null when the file is not there
+    traffic, traffic_note = None, None
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_wgrad.json')
+    if os.path.exists(pmc):
+        with open(pmc) as fh:
+            j = json.load(fh)
+        traffic = j['fetch_bytes_per_launch'] + j['write_bytes_per_launch']
+        traffic_note = 'bytes/launch, rocprofv3 PMC (profiles/r01_pmc_wgrad.json), not collected in this run'
     return {
         'bound': 'mfma', 'kernel': dom['name'], 'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': ach / PEAK_BF16_TFLOPS, 'traffic': None,
+        'frac': ach / PEAK_BF16_TFLOPS, 'traffic': traffic, 'traffic_note': traffic_note,
         'avg_launch_us': dom['ms'] / dom['launches'] * 1e3, 'launches_per_step': dom['launches'] / steps,
         'flop_per_launch': dom['flops'] / dom['launches'], 'ms_per_step': dom['ms'] / steps,
         'all_mfma_gemms': {'achieved': agg_fl / (agg_ms * 1e-3) * 1e-12,
