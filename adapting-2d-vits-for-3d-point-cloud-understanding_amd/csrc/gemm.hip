@@ -26,6 +26,7 @@ __device__ float g_zero_page[64];   // 256 B of zeros: LDS-DMA source for rows p
 
 #include "gemm_tn.h"
 #include "gemm_tn3.h"
+#include "gemm_tn4.h"
 #include "gemm_wgrad3.h"
 
 #define GEMM_THREADS 256
@@ -77,7 +78,9 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
         // the mid-tile-barrier schedule (3) keeps the plain bf16 epilogue at K = 768 (qkv 911 vs 884)
         // (with the per-wave streamed epilogue of gemm_tn3.h the ring kernel also wins the plain bf16 epilogue at
         //  K = 768: qkv 921 vs 882 for the mid-tile-barrier kernel, whose epilogue still runs as workgroup phases)
-        if (big256) v = 8;
+        //  The staggered 4-phase schedule of gemm_tn4.h (10) beats the ring kernel on every shape: qkv 1023 vs 883,
+        //  proj 512 vs 470, fc1 773 vs 695, fc2 968 vs 871, dfc2 840 vs 755, dfc1 1178 vs 1029.)
+        if (big256) v = 10;
         else if (p.N % T3_BN == 0 && big) v = 4;
         else v = 1;
     }
@@ -85,8 +88,8 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
         // Grid quantisation: with few rounds of big tiles (M = 256*257 and N = 768 give 771 tiles of 256x256 on
         // 256 CUs = 3 rounds + 3 tiles -> a 4th round for 0.4% of the work, measured -15..20%), peel the last
         // row tile(s) off and run them with the 128x128 configuration (many small workgroups, one short round).
-        if ((v == 3 || v == 4 || v == 5 || v == 7 || v == 8) && p.M % 256 == 0) {
-            const int bn = (v == 3 || v == 7 || v == 8) ? 256 : T3_BN, slots = (v == 3 || v == 7 || v == 8) ? 256 : 512;
+        if ((v == 3 || v == 4 || v == 5 || v == 7 || v == 8 || v == 10) && p.M % 256 == 0) {
+            const int bn = (v == 3 || v == 7 || v == 8 || v == 10) ? 256 : T3_BN, slots = (v == 3 || v == 7 || v == 8 || v == 10) ? 256 : 512;
             const int tiles_n = ceil_div(p.N, bn), tiles_m = p.M / 256;
             const long long total = (long long)tiles_m * tiles_n;
             const long long rounds = total / slots, rem = total % slots;
@@ -116,6 +119,15 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
             else hipLaunchKernelGGL((gemm_tn3_kernel<EPI, false, 128>), dim3(tiles), dim3(256), 0, st, p);
             P4P_LAUNCH_CHECK();
             return 0;
+        }
+        if (v == 10) {                                       // 256 x 256, staggered 4-phase schedule (gemm_tn4.h)
+            if (p.N % 256 == 0 && (unsigned long long)p.M * p.K * 2 < (1ull << 32) && (unsigned long long)p.N * p.K * 2 < (1ull << 32)) {
+                int tiles = ceil_div(p.M, 256) * (p.N / 256);
+                hipLaunchKernelGGL((gemm_tn4_kernel<EPI>), dim3(tiles), dim3(512), 0, st, p);
+                P4P_LAUNCH_CHECK();
+                return 0;
+            }
+            v = 8;
         }
         if ((v == 7 || v == 8) && p.N % 256 == 0) {          // 256 x 256, 8 waves, K-step 32 ring (1 workgroup per CU)
             int tiles = ceil_div(p.M, T3_BM) * (p.N / 256);

@@ -34,6 +34,152 @@ struct T3Frags {
     bf16x8 w[4];
 };
 
+// =================================================================================================
+// Epilogue shared by the 128 x 64-per-wave kernels (gemm_tn3_kernel, gemm_tn4_kernel).
+// lane holds, for (i,j): row ml = wm*128 + j*16 + li, cols nl = wn*64 + i*16 + 4g .. +3
+//
+// Streamed per WAVE in 8 slabs of 16 rows (j), with no workgroup barrier: the old epilogue ran as workgroup-wide
+// phases (all math, barrier, all stores, barrier ...) that every CU entered at the same moment, so HBM idled
+// during the math phases and the VALU during the store phases (K = 64 runs of the fused epilogues moved their bytes
+// at 2.8-3.8 TB/s, and the epilogue time simply added to the MFMA loop).  Here the stores of slab j drain while
+// slab j+1 is computed, and the loads a slab needs (residual / gelu') are issued one slab ahead.
+//   fp32 residual output: registers -> global directly (16 B per lane; the 4 column blocks i of a row complete
+//     256 contiguous bytes);  bf16 outputs: a wave-private 16 x 64 LDS slab turns the 8-B accumulator pieces
+//     into 16-B stores of whole 128-B row segments.
+// The caller guarantees that no wave reads the operand ring any more (the slabs live at `lds`, 4.5 KiB per wave).
+// =================================================================================================
+template <int EPI>
+__device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 (&acc)[4][8], char* lds, int tm, int m0,
+                                                     int n0, int wm, int wn, int wave, int lane) {
+    const int li = lane & 15, g = lane >> 4;
+    const int rowbase = m0 + wm * 128, colbase = n0 + wn * 64;
+    f32x4 bias4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bias4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias4[i] = *reinterpret_cast<const f32x4*>(p.bias + colbase + i * 16 + g * 4);
+    }
+
+    if (EPI == EPI_F32_RESID) {
+        const float* rsrc = p.resid ? p.resid + (size_t)colbase + g * 4 : nullptr;
+        float* dst = (float*)p.out + (size_t)colbase + g * 4;
+        auto row_of = [&](int j) { int m = rowbase + j * 16 + li; return m < p.M ? m : p.M - 1; };
+        f32x4 rnext[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rnext[i] = rsrc ? *reinterpret_cast<const f32x4*>(rsrc + (size_t)row_of(0) * p.N + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            f32x4 rcur[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rcur[i] = rnext[i];
+            if (j + 1 < 8 && rsrc) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rnext[i] = *reinterpret_cast<const f32x4*>(rsrc + (size_t)row_of(j + 1) * p.N + i * 16);
+            }
+            const int m = rowbase + j * 16 + li;
+            if (m < p.M) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<f32x4*>(dst + (size_t)m * p.N + i * 16) = (acc[i][j] + bias4[i]) + rcur[i];
+            }
+        }
+        return;
+    }
+
+    // ---- bf16 outputs
+    constexpr int SLAB_STRIDE = 144;                       // 128-B rows + 16: conflict-free 8-B writes, 16-B aligned reads
+    constexpr int SLAB_BYTES = 16 * SLAB_STRIDE;
+    char* slab = lds + wave * (2 * SLAB_BYTES);            // [out | pre] per wave
+    const int wr_off = li * SLAB_STRIDE + g * 8;           // + i*32
+    // the wave's own ds_writes and ds_reads execute in order; the fences only stop hipcc from moving them
+    auto wave_lds_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto flush = [&](const char* sl, __bf16* dstbase, int j) {     // 16 rows x 128 B -> global, 16 B per lane
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int r = h2 * 8 + (lane >> 3), c = lane & 7;
+            const int m = rowbase + j * 16 + r;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(sl + r * SLAB_STRIDE + c * 16);
+            if (m < p.M) *reinterpret_cast<u32x4*>(dstbase + (size_t)m * p.N + colbase + c * 8) = v;
+        }
+    };
+    const bool want_csum = EPI == EPI_BF16_DGELU && p.stats != nullptr;
+    f32x4 csum_all[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) csum_all[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x4 hnext[4];                                        // dGELU: gelu'(h) of the next slab, in accumulator layout
+    const __bf16* hsrc = EPI == EPI_BF16_DGELU ? p.pre + (size_t)colbase + g * 4 : nullptr;
+    auto hrow = [&](int j) { int m = rowbase + j * 16 + li; return m < p.M ? m : p.M - 1; };
+    if (EPI == EPI_BF16_DGELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hnext[i] = *reinterpret_cast<const bf16x4*>(hsrc + (size_t)hrow(0) * p.N + i * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bf16x4 hcur[4];
+        if (EPI == EPI_BF16_DGELU) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hcur[i] = hnext[i];
+            if (j + 1 < 8) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hnext[i] = *reinterpret_cast<const bf16x4*>(hsrc + (size_t)hrow(j + 1) * p.N + i * 16);
+            }
+        }
+        const bool row_ok = rowbase + j * 16 + li < p.M;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v = acc[i][j] + bias4[i];
+            if (EPI == EPI_BF16_GELU) {
+                // y = gelu(h) and gelu'(h) in one pass (`pre` receives the derivative: the backward epilogue only multiplies)
+                f32x4 dy;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float yy, dd;
+                    gelu_and_dgelu(v[r], yy, dd);
+                    v[r] = yy;
+                    dy[r] = dd;
+                }
+                if (p.pre) {
+                    bf16x4 w2 = {f2bf(dy[0]), f2bf(dy[1]), f2bf(dy[2]), f2bf(dy[3])};
+                    *reinterpret_cast<bf16x4*>(slab + SLAB_BYTES + wr_off + i * 32) = w2;
+                }
+            }
+            if (EPI == EPI_BF16_DGELU)
+                v = f32x4{v[0] * bf2f(hcur[i][0]), v[1] * bf2f(hcur[i][1]), v[2] * bf2f(hcur[i][2]), v[3] * bf2f(hcur[i][3])};
+            bf16x4 w = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            *reinterpret_cast<bf16x4*>(slab + wr_off + i * 32) = w;
+            if (EPI == EPI_BF16_DGELU && want_csum && row_ok)
+                csum_all[i] += f32x4{bf2f(w[0]), bf2f(w[1]), bf2f(w[2]), bf2f(w[3])};
+        }
+        wave_lds_sync();
+        if (EPI == EPI_BF16_GELU && p.pre) flush(slab + SLAB_BYTES, p.pre, j);
+        flush(slab, (__bf16*)p.out, j);
+        wave_lds_sync();
+    }
+    // dGELU with p.stats: column sums of the (rounded) output over this wave's 128 rows -> stats[2*tm + wm][n].  Their
+    // column sum is the fc1 bias gradient (autograd of nn.Linear.bias): no separate pass re-reading the 400-MB dh.
+    if (EPI == EPI_BF16_DGELU && want_csum) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 cs = csum_all[i];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                  // sum over the 16 rows li of this 16-lane group
+                float v = cs[r];
+                v += dpp_f32<0xB1>(v);
+                v += dpp_f32<0x4E>(v);
+                v += dpp_f32<0x141>(v);
+                v += dpp_f32<0x140>(v);
+                cs[r] = v;
+            }
+            if (li == 0) *reinterpret_cast<f32x4*>(p.stats + (size_t)(tm * 2 + wm) * p.N + colbase + i * 16 + g * 4) = cs;
+        }
+    }
+}
+
 template <int EPI, bool PAIR, int BN_, bool ILV = false>
 __global__ __launch_bounds__(BN_ * 2, 2) void gemm_tn3_kernel(GemmParams p) {
     constexpr int NWN = BN_ / 64, NW = 2 * NWN, NTHR = NW * 64;      // waves: 2 (M) x NWN (N), each 128 x 64
@@ -187,143 +333,6 @@ __global__ __launch_bounds__(BN_ * 2, 2) void gemm_tn3_kernel(GemmParams p) {
     }
 #undef T3_ITER
 
-    // =============================================================================================
-    // epilogue.  lane holds, for (i,j): row ml = wm*128 + j*16 + li, cols nl = wn*64 + i*16 + 4g .. +3
-    //
-    // Streamed per WAVE in 8 slabs of 16 rows (j), with no workgroup barrier: the old epilogue ran as workgroup-wide
-    // phases (all math, barrier, all stores, barrier ...) that every CU entered at the same moment, so HBM idled
-    // during the math phases and the VALU during the store phases (K = 64 runs of the fused epilogues moved their bytes
-    // at 2.8-3.8 TB/s, and the epilogue time simply added to the MFMA loop).  Here the stores of slab j drain while
-    // slab j+1 is computed, and the loads a slab needs (residual / gelu') are issued one slab ahead.
-    //   fp32 residual output: registers -> global directly (16 B per lane; the 4 column blocks i of a row complete
-    //     256 contiguous bytes);  bf16 outputs: a wave-private 16 x 64 LDS slab turns the 8-B accumulator pieces
-    //     into 16-B stores of whole 128-B row segments.
-    // After the last barrier of the K loop no wave reads the ring any more, so the slabs may live anywhere in LDS.
-    // =============================================================================================
-    const int rowbase = m0 + wm * 128, colbase = n0 + wn * 64;
-    f32x4 bias4[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        bias4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bias4[i] = *reinterpret_cast<const f32x4*>(p.bias + colbase + i * 16 + g * 4);
-    }
-
-    if (EPI == EPI_F32_RESID) {
-        const float* rsrc = p.resid ? p.resid + (size_t)colbase + g * 4 : nullptr;
-        float* dst = (float*)p.out + (size_t)colbase + g * 4;
-        auto row_of = [&](int j) { int m = rowbase + j * 16 + li; return m < p.M ? m : p.M - 1; };
-        f32x4 rnext[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rnext[i] = rsrc ? *reinterpret_cast<const f32x4*>(rsrc + (size_t)row_of(0) * p.N + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            f32x4 rcur[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) rcur[i] = rnext[i];
-            if (j + 1 < 8 && rsrc) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rnext[i] = *reinterpret_cast<const f32x4*>(rsrc + (size_t)row_of(j + 1) * p.N + i * 16);
-            }
-            const int m = rowbase + j * 16 + li;
-            if (m < p.M) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<f32x4*>(dst + (size_t)m * p.N + i * 16) = (acc[i][j] + bias4[i]) + rcur[i];
-            }
-        }
-        return;
-    }
-
-    // ---- bf16 outputs
-    constexpr int SLAB_STRIDE = 144;                       // 128-B rows + 16: conflict-free 8-B writes, 16-B aligned reads
-    constexpr int SLAB_BYTES = 16 * SLAB_STRIDE;
-    char* slab = lds + wave * (2 * SLAB_BYTES);            // [out | pre] per wave
-    const int wr_off = li * SLAB_STRIDE + g * 8;           // + i*32
-    // the wave's own ds_writes and ds_reads execute in order; the fences only stop hipcc from moving them
-    auto wave_lds_sync = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-    auto flush = [&](const char* sl, __bf16* dstbase, int j) {     // 16 rows x 128 B -> global, 16 B per lane
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            const int r = h2 * 8 + (lane >> 3), c = lane & 7;
-            const int m = rowbase + j * 16 + r;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(sl + r * SLAB_STRIDE + c * 16);
-            if (m < p.M) *reinterpret_cast<u32x4*>(dstbase + (size_t)m * p.N + colbase + c * 8) = v;
-        }
-    };
-    const bool want_csum = EPI == EPI_BF16_DGELU && p.stats != nullptr;
-    f32x4 csum_all[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) csum_all[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    bf16x4 hnext[4];                                        // dGELU: gelu'(h) of the next slab, in accumulator layout
-    const __bf16* hsrc = EPI == EPI_BF16_DGELU ? p.pre + (size_t)colbase + g * 4 : nullptr;
-    auto hrow = [&](int j) { int m = rowbase + j * 16 + li; return m < p.M ? m : p.M - 1; };
-    if (EPI == EPI_BF16_DGELU) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) hnext[i] = *reinterpret_cast<const bf16x4*>(hsrc + (size_t)hrow(0) * p.N + i * 16);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        bf16x4 hcur[4];
-        if (EPI == EPI_BF16_DGELU) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) hcur[i] = hnext[i];
-            if (j + 1 < 8) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) hnext[i] = *reinterpret_cast<const bf16x4*>(hsrc + (size_t)hrow(j + 1) * p.N + i * 16);
-            }
-        }
-        const bool row_ok = rowbase + j * 16 + li < p.M;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x4 v = acc[i][j] + bias4[i];
-            if (EPI == EPI_BF16_GELU) {
-                // y = gelu(h) and gelu'(h) in one pass (`pre` receives the derivative: the backward epilogue only multiplies)
-                f32x4 dy;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float yy, dd;
-                    gelu_and_dgelu(v[r], yy, dd);
-                    v[r] = yy;
-                    dy[r] = dd;
-                }
-                if (p.pre) {
-                    bf16x4 w2 = {f2bf(dy[0]), f2bf(dy[1]), f2bf(dy[2]), f2bf(dy[3])};
-                    *reinterpret_cast<bf16x4*>(slab + SLAB_BYTES + wr_off + i * 32) = w2;
-                }
-            }
-            if (EPI == EPI_BF16_DGELU)
-                v = f32x4{v[0] * bf2f(hcur[i][0]), v[1] * bf2f(hcur[i][1]), v[2] * bf2f(hcur[i][2]), v[3] * bf2f(hcur[i][3])};
-            bf16x4 w = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-            *reinterpret_cast<bf16x4*>(slab + wr_off + i * 32) = w;
-            if (EPI == EPI_BF16_DGELU && want_csum && row_ok)
-                csum_all[i] += f32x4{bf2f(w[0]), bf2f(w[1]), bf2f(w[2]), bf2f(w[3])};
-        }
-        wave_lds_sync();
-        if (EPI == EPI_BF16_GELU && p.pre) flush(slab + SLAB_BYTES, p.pre, j);
-        flush(slab, (__bf16*)p.out, j);
-        wave_lds_sync();
-    }
-    // dGELU with p.stats: column sums of the (rounded) output over this wave's 128 rows -> stats[2*tm + wm][n].  Their
-    // column sum is the fc1 bias gradient (autograd of nn.Linear.bias): no separate pass re-reading the 400-MB dh.
-    if (EPI == EPI_BF16_DGELU && want_csum) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x4 cs = csum_all[i];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {                  // sum over the 16 rows li of this 16-lane group
-                float v = cs[r];
-                v += dpp_f32<0xB1>(v);
-                v += dpp_f32<0x4E>(v);
-                v += dpp_f32<0x141>(v);
-                v += dpp_f32<0x140>(v);
-                cs[r] = v;
-            }
-            if (li == 0) *reinterpret_cast<f32x4*>(p.stats + (size_t)(tm * 2 + wm) * p.N + colbase + i * 16 + g * 4) = cs;
-        }
-    }
+    __builtin_amdgcn_sched_barrier(0);
+    tile_epilogue_128x64<EPI>(p, acc, lds, tm, m0, n0, wm, wn, wave, lane);
 }

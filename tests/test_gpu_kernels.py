@@ -168,7 +168,7 @@ def test_gemm_tn_exact_on_integer_data(M, N, K):
     assert torch.equal(got32, 2 * want + bias)
 
 
-@pytest.mark.parametrize('variant', [3, 4, 8])
+@pytest.mark.parametrize('variant', [3, 4, 8, 10])
 @pytest.mark.parametrize('M', [300 * 256, 300 * 256 - 100])
 def test_gemm_tn_big_tile_kernels_exact_on_integer_data(M, variant):
     """The 256-row tile kernels (mid-tile-barrier, 256x128 ring, 256x256 ring) on a grid of 600 tiles
@@ -233,7 +233,7 @@ def test_gemm_tn_epilogues_random():
     torch.testing.assert_close(st.sum(0)[0], ref.sum(0), rtol=1e-4, atol=1e-2)
 
 
-@pytest.mark.parametrize('variant', [0, 1, 3, 4, 6, 8])
+@pytest.mark.parametrize('variant', [0, 1, 3, 4, 6, 8, 10])
 @pytest.mark.parametrize('M,N,K', [(777, 512, 256), (66 * 256, 768, 256), (2049, 256, 128), (300 * 256, 512, 128)])
 def test_gemm_tn_dgelu_fused_bias_gradient(M, N, K, variant):
     """EPI_BF16_DGELU with want_colsum: the column sums of the stored (bf16) output, from the GEMM epilogue on the ring
