@@ -36,6 +36,27 @@ __device__ float g_zero_page[64];   // 256 B of zeros: LDS-DMA source for rows p
 static int g_gemm_variant = 0;
 extern "C" int p4p_set_gemm_variant(int v) { int o = g_gemm_variant; g_gemm_variant = v; return o; }
 
+// ---- split-K for the short, wide tail launches (few workgroups, long K loop: latency-bound at one K-step per ~0.5 us)
+// out[m][n] = sum_s part[s][m][n] + bias[n] (+ resid[m][n]), fixed order; fp32 or bf16 output
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int splits, long long plane,
+                                                            const float* __restrict__ bias, const float* __restrict__ resid,
+                                                            void* __restrict__ out, int out_f32, int N) {
+    const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= plane) return;
+    f32x4 v = *reinterpret_cast<const f32x4*>(part + e);
+    for (int s = 1; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(part + (size_t)s * plane + e);
+    if (bias) v += *reinterpret_cast<const f32x4*>(bias + (int)(e % N));
+    if (resid) v += *reinterpret_cast<const f32x4*>(resid + e);
+    if (out_f32) {
+        *reinterpret_cast<f32x4*>((float*)out + e) = v;
+    } else {
+        bf16x4 w = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        *reinterpret_cast<bf16x4*>((__bf16*)out + e) = w;
+    }
+}
+static float* g_splitk_ws = nullptr;       // library-owned scratch for the split-K planes (a few MB; one process per GPU)
+static size_t g_splitk_ws_floats = 0;
+
 template <int BM_, int BN_, int WAVES_M, int WAVES_N, int EPI, bool PIN = false, int ABL = 0>
 static int launch_cfg(const GemmParams& p, hipStream_t st) {
     int tiles = ceil_div(p.M, BM_) * ceil_div(p.N, BN_);
@@ -108,7 +129,40 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
                 g_gemm_variant = v;                                     // main part: no further peeling (rem == 0)
                 int rc = launch_tn_inner<EPI>(a, st);
                 g_gemm_variant = 6;                                     // 64x64 tiles: 4x more workgroups for the short tail
-                if (!rc) rc = launch_tn_inner<EPI>(b, st);
+                if (!rc) {
+                    int splits = 1;
+                    if constexpr (EPI == EPI_BF16 || EPI == EPI_F32_RESID) {
+                        static const bool no_splitk = getenv("P4P_NO_SPLITK") != nullptr;    // A/B switch for tools/ab_bench.sh
+                        if (p.K >= 1536 && p.N % 4 == 0 && !no_splitk) {    // long K: slices of 768 (or 512) columns
+                            splits = p.K % 768 == 0 ? p.K / 768 : (p.K % 512 == 0 ? p.K / 512 : 1);
+                            if (splits > 8) splits = 1;
+                        }
+                    }
+                    if (splits > 1) {
+                        const size_t plane = (size_t)b.M * b.N, need = plane * splits;
+                        if (need > g_splitk_ws_floats) {
+                            if (g_splitk_ws) P4P_HIP(hipFree(g_splitk_ws));
+                            g_splitk_ws = nullptr;
+                            g_splitk_ws_floats = 0;
+                            P4P_HIP(hipMalloc(&g_splitk_ws, need * sizeof(float)));
+                            g_splitk_ws_floats = need;
+                        }
+                        GemmParams c = b;
+                        c.K = p.K / splits;
+                        c.out = g_splitk_ws;
+                        c.bias = nullptr;
+                        c.resid = nullptr;
+                        int tiles = ceil_div(c.M, 64) * ceil_div(c.N, 64);
+                        hipLaunchKernelGGL((gemm_tn2_kernel<64, 64, 2, 2, EPI_F32_RESID, false, 0>), dim3(tiles, splits), dim3(256), 0, st, c);
+                        P4P_LAUNCH_CHECK();
+                        hipLaunchKernelGGL(splitk_finish_kernel, dim3(ceil_div((long long)plane / 4, 256)), dim3(256), 0, st,
+                                           g_splitk_ws, splits, (long long)plane, b.bias, b.resid, b.out,
+                                           EPI == EPI_F32_RESID ? 1 : 0, b.N);
+                        P4P_LAUNCH_CHECK();
+                    } else {
+                        rc = launch_tn_inner<EPI>(b, st);
+                    }
+                }
                 g_gemm_variant = saved;
                 return rc;
             }
@@ -169,7 +223,7 @@ extern "C" int p4p_gemm_tn_bf16(int epi, const void* A, const void* W, void* out
     P4P_CHECK(N % 8 == 0, "p4p_gemm_tn_bf16: N=%d must be a multiple of 8", N);
     GemmParams p;
     p.A = (const __bf16*)A; p.W = (const __bf16*)W; p.out = out; p.bias = bias; p.resid = resid;
-    p.pre = (__bf16*)pre; p.rowgrp = rowgrp; p.stats = stats; p.M = M; p.N = N; p.K = K; p.group = group;
+    p.pre = (__bf16*)pre; p.rowgrp = rowgrp; p.stats = stats; p.M = M; p.N = N; p.K = K; p.group = group; p.ldk = K;
     hipStream_t st = (hipStream_t)stream;
     struct ProfScope {      // gemm_tn: brackets the (one or two, when the tail is peeled) launches of this call
         hipStream_t s; bool on;

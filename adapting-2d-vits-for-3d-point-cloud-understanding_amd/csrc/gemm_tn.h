@@ -26,6 +26,7 @@ struct GemmParams {
     const float* rowgrp;   // [M/group, N] f32        (EPI_BF16_ROWGROUP)
     float* stats;          // [tiles_m][2][N] f32 partial column sums / sums of squares
     int M, N, K, group;
+    int ldk;               // row stride of A and W in elements (= K, except for the split-K launches of gemm_tn2_kernel)
 };
 
 enum {
@@ -85,6 +86,9 @@ void gemm_tn2_kernel(GemmParams p) {
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
     const int m0 = tm * BM_, n0 = tn * BN_;
     const int nk = p.K / 64;
+    // split-K launch (gridDim.y > 1): slice y contracts columns [y*K, (y+1)*K) of the ldk-wide operands into its own
+    // fp32 output plane (EPI_F32_RESID without bias / residual); splitk_finish_kernel adds the planes in a fixed order
+    const size_t koff = (size_t)blockIdx.y * p.K;
 
     // ---- LDS-DMA staging: piece q of the stage covers 8 rows; pieces [0, BM/8) are A rows, the rest W rows
     const int rin = lane >> 3;
@@ -97,7 +101,7 @@ void gemm_tn2_kernel(GemmParams p) {
         int r = isA ? m0 + piece * 8 + rin : n0 + (piece - BM_ / 8) * 8 + rin;
         const int lim = isA ? p.M : p.N;
         r = r < lim ? r : lim - 1;
-        src[q] = (isA ? p.A : p.W) + (size_t)r * p.K + chunk * 8;
+        src[q] = (isA ? p.A : p.W) + (size_t)r * p.ldk + koff + chunk * 8;
     }
     auto stage = [&](int kt, char* buf) {
 #pragma unroll
@@ -208,7 +212,7 @@ void gemm_tn2_kernel(GemmParams p) {
             if (EPI == EPI_F32_RESID) {
                 if (ok) {
                     if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
-                    *reinterpret_cast<f32x4*>((float*)p.out + o) = v;
+                    *reinterpret_cast<f32x4*>((float*)p.out + (size_t)blockIdx.y * p.M * p.N + o) = v;
                 }
                 continue;
             }

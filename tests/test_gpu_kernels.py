@@ -199,6 +199,23 @@ def test_gemm_tn_big_tile_kernels_exact_on_integer_data(M, variant):
     assert torch.equal(dgelu, ref_dgelu)
 
 
+@pytest.mark.parametrize('K', [2304, 3072])
+def test_gemm_tn_split_k_tail_exact_on_integer_data(K):
+    """M = 257 panels of 256 rows, N = 768: three full rounds of 256x256 tiles plus one panel, which is peeled off and --
+    for K >= 1536 -- contracted in K slices by the 64x64 kernel into fp32 planes that a finishing kernel adds in a fixed
+    order (bias / residual / bf16 cast applied there).  Exact on integer operands, including the peeled rows."""
+    M, N = 257 * 256, 768
+    a = _int_bf16((M, K), -2, 2, 21).to(DEV)
+    w = (_int_bf16((N, K), -1, 1, 22).to(DEV) * (torch.rand(N, K, device=DEV) < 0.05)).to(torch.bfloat16).contiguous()
+    want = a.float() @ w.float().t()
+    assert float(want.abs().max()) <= 256
+    bias = torch.arange(N, device=DEV, dtype=torch.float32) % 5 - 2
+    got = ops.gemm_tn(a, w, ops.EPI_BF16, bias=bias)
+    assert torch.equal(got.float(), want + bias)
+    got32 = ops.gemm_tn(a, w, ops.EPI_F32_RESID, bias=bias, resid=want.clone())
+    assert torch.equal(got32, 2 * want + bias)
+
+
 def test_gemm_tn_epilogues_random():
     M, N, K = 777, 320, 256
     g = torch.Generator().manual_seed(0)
