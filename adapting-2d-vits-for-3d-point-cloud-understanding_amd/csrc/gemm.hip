@@ -85,7 +85,14 @@ template <int EPI>
 static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
     constexpr bool STATS = EPI == EPI_BF16_ROWGROUP || EPI == EPI_BF16_STATS;
     int v = g_gemm_variant;
-    if (STATS) v = 1;                         // statistics rows are per 128-row tile (p4p_gemm_tn_stats_rows)
+    const bool fits_tn4 = p.N % 256 == 0 && (long long)ceil_div(p.M, 256) * (p.N / 256) >= 256 &&
+                          (unsigned long long)p.M * p.K * 2 < (1ull << 32) && (unsigned long long)p.N * p.K * 2 < (1ull << 32);
+    if (STATS) {
+        // statistics rows are per 128-row block (p4p_gemm_tn_stats_rows): the 128x128 kernel, or the 256x256 staggered
+        // kernel whose two wave rows own one block each
+        if (v == 0 || v == 10) v = fits_tn4 ? 10 : 1;
+        else v = 1;
+    }
     if (v == 0) {
         // measured on MI355X at the ViT-B shapes (tools/gemm_bench.py, random data):
         //   plain bf16 epilogue  : 256x256 tile wins (940-1000 TFLOP/s vs 830 / 700)
@@ -104,6 +111,13 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
         if (big256) v = 10;
         else if (p.N % T3_BN == 0 && big) v = 4;
         else v = 1;
+    }
+    if constexpr (STATS) {
+        if (v == 10) {
+            hipLaunchKernelGGL((gemm_tn4_kernel<EPI>), dim3(ceil_div(p.M, 256) * (p.N / 256)), dim3(512), 0, st, p);
+            P4P_LAUNCH_CHECK();
+            return 0;
+        }
     }
     if constexpr (!STATS) {
         // Grid quantisation: with few rounds of big tiles (M = 256*257 and N = 768 give 771 tiles of 256x256 on

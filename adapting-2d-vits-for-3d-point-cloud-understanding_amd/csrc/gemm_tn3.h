@@ -107,9 +107,10 @@ __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 
         }
     };
     const bool want_csum = EPI == EPI_BF16_DGELU && p.stats != nullptr;
-    f32x4 csum_all[4];
+    constexpr bool STATS = EPI == EPI_BF16_ROWGROUP || EPI == EPI_BF16_STATS;   // column sums + sums of squares (BatchNorm)
+    f32x4 csum_all[4], csq_all[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) csum_all[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) csum_all[i] = csq_all[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     bf16x4 hnext[4];                                        // dGELU: gelu'(h) of the next slab, in accumulator layout
     const __bf16* hsrc = EPI == EPI_BF16_DGELU ? p.pre + (size_t)colbase + g * 4 : nullptr;
@@ -154,6 +155,10 @@ __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 
             *reinterpret_cast<bf16x4*>(slab + wr_off + i * 32) = w;
             if (EPI == EPI_BF16_DGELU && want_csum && row_ok)
                 csum_all[i] += f32x4{bf2f(w[0]), bf2f(w[1]), bf2f(w[2]), bf2f(w[3])};
+            if (STATS && row_ok) {                          // fp32 values before rounding, as in gemm_tn2_kernel
+                csum_all[i] += v;
+                csq_all[i] += v * v;
+            }
         }
         wave_lds_sync();
         if (EPI == EPI_BF16_GELU && p.pre) flush(slab + SLAB_BYTES, p.pre, j);
@@ -162,6 +167,26 @@ __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 
     }
     // dGELU with p.stats: column sums of the (rounded) output over this wave's 128 rows -> stats[2*tm + wm][n].  Their
     // column sum is the fc1 bias gradient (autograd of nn.Linear.bias): no separate pass re-reading the 400-MB dh.
+    // EPI_BF16_ROWGROUP / EPI_BF16_STATS: stats[ceil(M/128)][2][N], one row pair per 128-row block = per wave row
+    if (STATS && 2 * tm + wm < (p.M + 127) / 128) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 cs = csum_all[i], cq = csq_all[i];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = cs[r], b = cq[r];
+                a += dpp_f32<0xB1>(a); a += dpp_f32<0x4E>(a); a += dpp_f32<0x141>(a); a += dpp_f32<0x140>(a);
+                b += dpp_f32<0xB1>(b); b += dpp_f32<0x4E>(b); b += dpp_f32<0x141>(b); b += dpp_f32<0x140>(b);
+                cs[r] = a;
+                cq[r] = b;
+            }
+            if (li == 0) {
+                float* row = p.stats + (size_t)(2 * tm + wm) * 2 * p.N + colbase + i * 16 + g * 4;
+                *reinterpret_cast<f32x4*>(row) = cs;
+                *reinterpret_cast<f32x4*>(row + p.N) = cq;
+            }
+        }
+    }
     if (EPI == EPI_BF16_DGELU && want_csum) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

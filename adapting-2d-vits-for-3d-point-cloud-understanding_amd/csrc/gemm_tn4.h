@@ -77,14 +77,20 @@ __global__ __launch_bounds__(512) void gemm_tn4_kernel(GemmParams p) {
         st_slot = st_slot == T4_SLOTS - 1 ? 0 : st_slot + 1;
     };
 
-    f32x4 acc[4][8];     // [n-tile][m-tile]
+    // ---- fragment addressing: row li of a 16-row block, 16-B chunk (4*kh + g) ^ (li & 7)
+    const int li = lane & 15, g = lane >> 4;
+    f32x4 acc[4][8];     // [n-tile][m-tile]; EPI_BF16_ROWGROUP: the per-group addend is the initial value (see gemm_tn2_kernel)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 8; ++j) {
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (EPI == EPI_BF16_ROWGROUP) {
+                const int m = m0 + wm * 128 + j * 16 + li;
+                if (m < p.M) acc[i][j] = *reinterpret_cast<const f32x4*>(p.rowgrp + (size_t)(m / p.group) * p.N + n0 + wn * 64 + i * 16 + g * 4);
+            }
+        }
 
-    // ---- fragment addressing: row li of a 16-row block, 16-B chunk (4*kh + g) ^ (li & 7)
-    const int li = lane & 15, g = lane >> 4;
     const int fo0 = li * 128 + ((g ^ (li & 7)) << 4), fo1 = fo0 ^ 64;
     const int a_half = 2 + wm, b_half = wn >> 1, b_row = (wn & 1) * 8192;     // half-tile roles, byte offset of the wave's 64 W rows
     int c_slot = 0;                                        // ring slot of B0 of the K-tile being consumed

@@ -216,6 +216,36 @@ def test_gemm_tn_split_k_tail_exact_on_integer_data(K):
     assert torch.equal(got32, 2 * want + bias)
 
 
+@pytest.mark.parametrize('M', [70000, 256 * 300])
+def test_gemm_tn_statistics_epilogues_on_the_big_tile_kernel(M):
+    """EPI_BF16_ROWGROUP / EPI_BF16_STATS at tokenizer-like sizes take the 256x256 staggered kernel: same outputs as the
+    128x128 kernel (bit-identical: same k order), statistics rows per 128-row block equal up to summation order."""
+    from p4p_amd import _lib
+    N, K, grp = 512, 256, 16
+    g = torch.Generator().manual_seed(M)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(torch.bfloat16).to(DEV)
+    rg = torch.randn(M // grp, N, generator=g).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    lib = _lib.lib()
+    old = lib.p4p_set_gemm_variant(1)
+    try:
+        o1, s1 = ops.gemm_tn(a, w, ops.EPI_BF16_ROWGROUP, rowgrp=rg, group=grp)
+        o2, s2 = ops.gemm_tn(a, w, ops.EPI_BF16_STATS, bias=bias)
+        lib.p4p_set_gemm_variant(0)
+        p1, t1 = ops.gemm_tn(a, w, ops.EPI_BF16_ROWGROUP, rowgrp=rg, group=grp)
+        p2, t2 = ops.gemm_tn(a, w, ops.EPI_BF16_STATS, bias=bias)
+    finally:
+        lib.p4p_set_gemm_variant(old)
+    assert torch.equal(o1, p1) and torch.equal(o2, p2)
+    assert s1.shape == t1.shape and s2.shape == t2.shape
+    torch.testing.assert_close(t1, s1, rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(t2, s2, rtol=1e-4, atol=1e-2)
+    full = a.float() @ w.float().t() + bias
+    torch.testing.assert_close(t2.sum(0)[0], full.sum(0), rtol=1e-4, atol=0.5)
+    torch.testing.assert_close(t2.sum(0)[1], (full * full).sum(0), rtol=1e-4, atol=0.5)
+
+
 def test_gemm_tn_epilogues_random():
     M, N, K = 777, 320, 256
     g = torch.Generator().manual_seed(0)
