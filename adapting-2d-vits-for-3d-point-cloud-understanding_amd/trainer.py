@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from .ddp import broadcast_parameters, build_reducer
+from .optim import FusedAdamW
 from .pix4point import Pix4Point
 
 
@@ -108,8 +109,13 @@ class Pix4PointTrainer:
     def _init_optimizer(self) -> None:
         t = self.train_config
         self.criterion = nn.CrossEntropyLoss()
-        self.optimizer = optim.AdamW(self.model.get_param_groups(), lr=t['learning_rate'], weight_decay=t['weight_decay'],
-                                     fused=True)
+        # same update rule, groups and state_dict layout as the reference's optim.AdamW (:104-106); clip + step are three
+        # launches (p4p_amd.optim).  P4P_TORCH_OPTIM=1 keeps stock torch (A/B, debugging).
+        if os.environ.get('P4P_TORCH_OPTIM'):
+            self.optimizer = optim.AdamW(self.model.get_param_groups(), lr=t['learning_rate'], weight_decay=t['weight_decay'],
+                                         fused=True)
+        else:
+            self.optimizer = FusedAdamW(self.model.get_param_groups(), lr=t['learning_rate'], weight_decay=t['weight_decay'])
         warm = optim.lr_scheduler.LambdaLR(self.optimizer, lr_lambda=lambda epoch: (epoch + 1) / t['warmup_epochs'])
         cos = optim.lr_scheduler.CosineAnnealingLR(self.optimizer, t['t_max'], eta_min=t['min_lr'])
         self.scheduler = optim.lr_scheduler.SequentialLR(self.optimizer, schedulers=[warm, cos],
@@ -135,8 +141,11 @@ class Pix4PointTrainer:
         loss.backward()
         if self.reducer is not None:
             self.reducer.finish()
-        torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.train_config['grad_norm_clip'], foreach=True)
-        self.optimizer.step()
+        if isinstance(self.optimizer, FusedAdamW):
+            self.optimizer.step(max_norm=self.train_config['grad_norm_clip'])
+        else:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.train_config['grad_norm_clip'], foreach=True)
+            self.optimizer.step()
         return loss, logits
 
     # ---- reference :135-151

@@ -80,7 +80,12 @@ class Stepper:
         self.model.train()
         broadcast_parameters(self.model)
         self.reducer = build_reducer(self.model) if distributed else None
-        self.opt = torch.optim.AdamW(self.model.get_param_groups(), lr=5e-4, weight_decay=5e-2, fused=True)
+        from p4p_amd.optim import FusedAdamW
+        if os.environ.get('P4P_TORCH_OPTIM'):         # A/B: stock torch clip + fused AdamW
+            self.opt = torch.optim.AdamW(self.model.get_param_groups(), lr=5e-4, weight_decay=5e-2, fused=True)
+        else:
+            self.opt = FusedAdamW(self.model.get_param_groups(), lr=5e-4, weight_decay=5e-2)
+        self.fused_opt = isinstance(self.opt, FusedAdamW)
         self.crit = torch.nn.CrossEntropyLoss()
 
     def step(self, pts, labels, start):
@@ -92,8 +97,11 @@ class Stepper:
         loss.backward()
         if self.reducer is not None:
             self.reducer.finish()
-        torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=10, foreach=True)
-        self.opt.step()
+        if self.fused_opt:
+            self.opt.step(max_norm=10)               # clip_grad_norm_ + AdamW in three launches (p4p_amd.optim)
+        else:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=10, foreach=True)
+            self.opt.step()
         return loss
 
 

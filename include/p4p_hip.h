@@ -158,6 +158,18 @@ int p4p_prof_collect(double* out);
 int p4p_set_gemm_variant(int v);
 int p4p_set_wgrad_wide(int v);
 
+/* ---- train-step tail: clip_grad_norm_ + AdamW over all parameter tensors (src/train/pix4point_trainer.py:164-167) ----
+   tensors: device array of {float* p; const float* g; float* m; float* v; long long n; float lr, wd} (48 B each);
+   chunks: device array of {int tensor; int offset} in units of p4p_opt_chunk_elems() elements, never straddling tensors. */
+int p4p_opt_chunk_elems(void);
+/* partial[c] = sum of squares of gradient chunk c */
+int p4p_grad_sumsq(const void* tensors, const void* chunks, int nchunks, float* partial, void* stream);
+/* coef_and_norm[0] = min(1, max_norm / (norm + 1e-6)), [1] = norm = sqrt(sum partial)  (torch.nn.utils.clip_grad_norm_) */
+int p4p_clip_coef(const float* partial, int nchunks, float max_norm, float* coef_and_norm, void* stream);
+/* torch.optim.AdamW update (amsgrad=False) with g scaled by *coef (NULL = 1); bc1 = 1 - beta1^t, bc2 = 1 - beta2^t */
+int p4p_adamw_step(const void* tensors, const void* chunks, int nchunks, const float* coef, float beta1, float beta2,
+                   float eps, float bc1, float bc2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

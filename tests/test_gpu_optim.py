@@ -1,0 +1,78 @@
+"""FusedAdamW (csrc/optim.hip) against stock torch: same update rule as torch.optim.AdamW and the same clipping as
+torch.nn.utils.clip_grad_norm_, checked on parameter sets with the reference's decay / no-decay groups, odd sizes and
+unaligned views; state_dict round trip with torch.optim.AdamW in both directions."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _params(seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(768, 768), (2304,), (5,), (3, 7, 11), (1,), (40000,), (16385,), (129, 3)]
+    return [torch.nn.Parameter(torch.randn(*s, generator=g).to(dev)) for s in shapes]
+
+
+def _grads(ps, seed, scale):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(p.shape, generator=g) * scale for p in ps]
+
+
+@pytest.mark.parametrize('max_norm,scale', [(None, 1.0), (10.0, 1.0), (10.0, 1e-3)])
+def test_matches_torch_adamw_and_clip(max_norm, scale):
+    from p4p_amd.optim import FusedAdamW
+    ours, ref = _params(0, DEV), _params(0, 'cpu')
+    groups = lambda ps: [{'params': ps[:4], 'weight_decay': 5e-2}, {'params': ps[4:], 'weight_decay': 0.0, 'lr': 2e-3}]
+    opt = FusedAdamW(groups(ours), lr=5e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2)
+    tor = torch.optim.AdamW(groups(ref), lr=5e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-2)
+    for it in range(4):
+        gs = _grads(ref, 100 + it, scale)
+        for p, q, g in zip(ours, ref, gs):
+            p.grad = g.to(DEV)
+            q.grad = g.clone()
+        want_norm = None
+        if max_norm is not None:
+            want_norm = torch.nn.utils.clip_grad_norm_(ref, max_norm)
+        tor.step()
+        got_norm = opt.step(max_norm=max_norm)
+        if max_norm is not None:
+            torch.testing.assert_close(got_norm.cpu(), want_norm, rtol=1e-5, atol=1e-7)
+            for p, g in zip(ours, gs):
+                assert torch.equal(p.grad.cpu(), g)                  # gradients themselves stay unscaled (documented)
+        for p, q in zip(ours, ref):
+            torch.testing.assert_close(p.detach().cpu(), q.detach(), rtol=2e-6, atol=2e-7)
+    for p, q in zip(ours, ref):
+        torch.testing.assert_close(opt.state[p]['exp_avg'].cpu(), tor.state[q]['exp_avg'], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(opt.state[p]['exp_avg_sq'].cpu(), tor.state[q]['exp_avg_sq'], rtol=1e-5, atol=1e-7)
+
+
+def test_state_dict_round_trip_with_torch_adamw():
+    from p4p_amd.optim import FusedAdamW
+    ours, ref = _params(1, DEV), _params(1, DEV)
+    opt = FusedAdamW([{'params': ours}], lr=1e-3, weight_decay=5e-2)
+    tor = torch.optim.AdamW([{'params': ref}], lr=1e-3, weight_decay=5e-2, fused=True)
+    for it in range(2):
+        for p, q, g in zip(ours, ref, _grads(ref, 7 + it, 1.0)):
+            p.grad, q.grad = g.to(DEV), g.to(DEV)
+        opt.step()
+        tor.step()
+    # torch -> ours and ours -> torch, then one more identical step each
+    opt2 = FusedAdamW([{'params': ours}], lr=1e-3, weight_decay=5e-2)
+    opt2.load_state_dict(tor.state_dict())
+    tor2 = torch.optim.AdamW([{'params': ref}], lr=1e-3, weight_decay=5e-2)
+    tor2.load_state_dict(opt.state_dict())
+    for p, q, g in zip(ours, ref, _grads(ref, 99, 1.0)):
+        p.grad, q.grad = g.to(DEV), g.to(DEV)
+    opt2.step()
+    tor2.step()
+    for p, q in zip(ours, ref):
+        torch.testing.assert_close(p.detach(), q.detach(), rtol=2e-6, atol=2e-7)
+
+
+def test_rejects_cpu_parameters():
+    from p4p_amd.optim import FusedAdamW
+    p = torch.nn.Parameter(torch.zeros(4))
+    p.grad = torch.ones(4)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        FusedAdamW([p]).step()
