@@ -128,7 +128,8 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
             const int tiles_n = ceil_div(p.N, bn), tiles_m = p.M / 256;
             const long long total = (long long)tiles_m * tiles_n;
             const long long rounds = total / slots, rem = total % slots;
-            if (rounds >= 1 && rounds <= 4 && rem > 0 && rem * 8 <= slots && rem % tiles_n == 0 && rem / tiles_n < tiles_m) {
+            static const int peel_max_rounds = getenv("P4P_PEEL_MAX_ROUNDS") ? atoi(getenv("P4P_PEEL_MAX_ROUNDS")) : 12;   // narrow N (<= 4 tiles per panel): measured at N=2048 (6 rounds + 3 tiles)
+            if (rounds >= 1 && rounds <= (tiles_n <= 4 ? peel_max_rounds : 4) && rem > 0 && rem * 8 <= slots && rem % tiles_n == 0 && rem / tiles_n < tiles_m) {
                 const int peel = (int)(rem / tiles_n) * 256;            // rows handled by the small-tile launch
                 GemmParams a = p, b = p;
                 a.M = p.M - peel;
