@@ -277,6 +277,80 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
     }
 }
 
+// Forward for short sequences (T <= RES_ROWS): one workgroup = one (b,h), all of K and V resident in LDS (2 x 34 KiB),
+// 8 waves that each take whole 16-query tiles (17 at T = 257) and run over the key tiles with NO further barrier or
+// staging wait.  The streaming kernel above spends its time on per-workgroup fixed latencies and one barrier + LDS-DMA
+// wait per 64-key tile (measured at B=256, T=257, H=12: 69 us with neither math nor staging in the loop, +60 us for the
+// staging, +67 us for the math, and the three do not overlap); here a workgroup pays one load latency for 17 x 5 tiles
+// of work and two workgroups share a CU.
+#define RES_ROWS 288          // ceil(257 / 32) * 32: the PV / dK contraction steps read 32 rows at a time
+#define RES_NW 8
+__global__ __launch_bounds__(RES_NW * 64, 4) void attn_fwd_res_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * RES_ROWS * 128];          // K rows | V rows
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const int T = p.T, D = p.D;
+    const size_t ld = (size_t)3 * D;
+    const __bf16* seq = p.qkv + (size_t)b * T * ld;
+    const float c = p.scale * 1.4426950408889634f;
+    char* klds = lds;
+    char* vlds = lds + RES_ROWS * 128;
+
+    // ---- stage K and V: 1-KiB pieces of 8 rows (rows past T repeat row T-1; they are masked below)
+    const int npieces = ((T + 31) >> 5) * 4;        // whole 32-row contraction steps: masked rows must still hold finite data (0 x NaN)
+    const int rin = lane >> 3, chunk = (lane & 7) ^ rin;
+    for (int pc = wave; pc < 2 * npieces; pc += RES_NW) {
+        const int isv = pc >= npieces, piece = isv ? pc - npieces : pc;
+        int r = piece * 8 + rin;
+        r = r < T ? r : T - 1;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(seq + (size_t)r * ld + (1 + isv) * D + h * HD + chunk * 8),
+                                         LDS_PTR((isv ? vlds : klds) + piece * 1024), 16, 0, 0);
+    }
+    // ---- this wave's query tiles (rotated per (b,h): the extra 17th tile does not always land on the same SIMD)
+    const int nqt = (T + 15) >> 4;
+    const int w0 = (wave + (bh >> 3)) & (RES_NW - 1);
+    constexpr int MAXQ = (RES_ROWS / 16 + RES_NW - 1) / RES_NW;          // 3
+    bf16x8 qf[MAXQ][2];
+#pragma unroll
+    for (int s = 0; s < MAXQ; ++s) {
+        const int qt = w0 + s * RES_NW;
+        int q = qt * 16 + i;
+        q = q < T ? q : T - 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[s][ks] = *reinterpret_cast<const bf16x8*>(seq + (size_t)q * ld + h * HD + ks * 32 + g * 8);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // own LDS-DMA pieces landed (vmcnt(0)), then publish
+    __syncthreads();
+
+    const int nkt = (T + 63) / 64, nfull = T / 64;
+#pragma unroll
+    for (int s = 0; s < MAXQ; ++s) {
+        const int qt = w0 + s * RES_NW;
+        if (qt >= nqt) break;
+        f32x4 o[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float m = -INFINITY, lsum = 0.f;
+        for (int kt = 0; kt < nfull; ++kt)
+            attn_fwd_tile<false>(klds + kt * TILE_BYTES, vlds + kt * TILE_BYTES, qf[s], o, m, lsum, c, kt * 64, T, lane);
+        if (nfull < nkt)
+            attn_fwd_tile<true>(klds + nfull * TILE_BYTES, vlds + nfull * TILE_BYTES, qf[s], o, m, lsum, c, nfull * 64, T, lane);
+        const float l = xor_lanes_sum(lsum);
+        const float inv = 1.0f / l;
+        const int q = qt * 16 + i;
+        if (q < T) {
+            __bf16* dst = p.out + ((size_t)b * T + q) * D + h * HD;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                bf16x4 w = {f2bf(o[d][0] * inv), f2bf(o[d][1] * inv), f2bf(o[d][2] * inv), f2bf(o[d][3] * inv)};
+                *reinterpret_cast<bf16x4*>(dst + d * 16 + 4 * g) = w;
+            }
+            if (g == 0 && p.lse2) p.lse2[((size_t)b * p.H + h) * T + q] = m + __builtin_amdgcn_logf(l);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // delta[b,h,t] = sum_d dO[t, h*64+d] * O[t, h*64+d]
 // ------------------------------------------------------------------------------------------------
@@ -525,6 +599,126 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv_kernel(AttnParam
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward for short sequences (T <= RES_ROWS), same idea as attn_fwd_res_kernel: one workgroup per (b,h), the
+// streamed operand pair resident in LDS, whole 16-row tiles per wave, one barrier in the whole kernel.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void res_stage_pair(const __bf16* __restrict__ src0, size_t ld0, const __bf16* __restrict__ src1,
+                                               size_t ld1, char* lds0, char* lds1, int T, int wave, int lane) {
+    const int npieces = ((T + 31) >> 5) * 4;        // whole 32-row contraction steps (rows past T repeat row T-1: finite data)
+    const int rin = lane >> 3, chunk = (lane & 7) ^ rin;
+    for (int pc = wave; pc < 2 * npieces; pc += RES_NW) {
+        const int second = pc >= npieces, piece = second ? pc - npieces : pc;
+        int r = piece * 8 + rin;
+        r = r < T ? r : T - 1;
+        const __bf16* src = second ? src1 + (size_t)r * ld1 : src0 + (size_t)r * ld0;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src + chunk * 8), LDS_PTR((second ? lds1 : lds0) + piece * 1024), 16, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(RES_NW * 64, 4) void attn_bwd_dq_res_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * RES_ROWS * 128];          // K rows | V rows
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const int T = p.T, D = p.D;
+    const size_t ld = (size_t)3 * D;
+    const __bf16* seq = p.qkv + (size_t)b * T * ld;
+    const float c = p.scale * 1.4426950408889634f;
+    char* klds = lds;
+    char* vlds = lds + RES_ROWS * 128;
+    res_stage_pair(seq + D + h * HD, ld, seq + 2 * D + h * HD, ld, klds, vlds, T, wave, lane);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+
+    const int nqt = (T + 15) >> 4, nkt = (T + 63) / 64, nfull = T / 64;
+    const int w0 = (wave + (bh >> 3)) & (RES_NW - 1);
+    for (int qt = w0; qt < nqt; qt += RES_NW) {
+        const int q = qt * 16 + i;
+        const int qc = q < T ? q : T - 1;
+        bf16x8 qf[2], dof[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(seq + (size_t)qc * ld + h * HD + ks * 32 + g * 8);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(p.dout + ((size_t)b * T + qc) * D + h * HD + ks * 32 + g * 8);
+        }
+        const size_t stat = ((size_t)b * p.H + h) * T + qc;
+        const float lse = p.lse2[stat], dl = p.delta[stat];
+        f32x4 dq[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nfull; ++kt)
+            attn_dq_tile<false>(klds + kt * TILE_BYTES, vlds + kt * TILE_BYTES, qf, dof, dq, c, lse, dl, 64, lane);
+        if (nfull < nkt)
+            attn_dq_tile<true>(klds + nfull * TILE_BYTES, vlds + nfull * TILE_BYTES, qf, dof, dq, c, lse, dl, T - nfull * 64, lane);
+        if (q < T) {
+            __bf16* dst = p.out + ((size_t)b * T + q) * ld + h * HD;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                bf16x4 w = {f2bf(dq[d][0] * p.scale), f2bf(dq[d][1] * p.scale), f2bf(dq[d][2] * p.scale), f2bf(dq[d][3] * p.scale)};
+                *reinterpret_cast<bf16x4*>(dst + d * 16 + 4 * g) = w;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(RES_NW * 64, 4) void attn_bwd_dkdv_res_kernel(AttnParams p) {
+    // Q rows | dO rows | per 64-query tile: lse2[64], delta[64]
+    __shared__ __attribute__((aligned(1024))) char lds[2 * RES_ROWS * 128 + (RES_ROWS / 64 + 1) * 512];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const int T = p.T, D = p.D;
+    const size_t ld = (size_t)3 * D;
+    const __bf16* seq = p.qkv + (size_t)b * T * ld;
+    const float c = p.scale * 1.4426950408889634f;
+    char* qlds = lds;
+    char* dolds = lds + RES_ROWS * 128;
+    float* stats = reinterpret_cast<float*>(lds + 2 * RES_ROWS * 128);
+    res_stage_pair(seq + h * HD, ld, p.dout + (size_t)b * T * D + h * HD, (size_t)D, qlds, dolds, T, wave, lane);
+    const int nqt = (T + 63) / 64, nfull = T / 64;
+    {
+        const float* lse_b = p.lse2 + ((size_t)b * p.H + h) * T;
+        const float* del_b = p.delta + ((size_t)b * p.H + h) * T;
+        for (int e = t; e < nqt * 64; e += RES_NW * 64) {
+            const int qq = e < T ? e : T - 1;
+            stats[(e >> 6) * 128 + (e & 63)] = lse_b[qq];
+            stats[(e >> 6) * 128 + 64 + (e & 63)] = del_b[qq];
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+
+    const int nkt16 = (T + 15) >> 4;
+    const int w0 = (wave + (bh >> 3)) & (RES_NW - 1);
+    for (int kt = w0; kt < nkt16; kt += RES_NW) {
+        const int key = kt * 16 + i;
+        const int kc = key < T ? key : T - 1;
+        bf16x8 kf[2], vf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            kf[ks] = *reinterpret_cast<const bf16x8*>(seq + (size_t)kc * ld + D + h * HD + ks * 32 + g * 8);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(seq + (size_t)kc * ld + 2 * D + h * HD + ks * 32 + g * 8);
+        }
+        f32x4 dk[4], dv[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) dk[d] = dv[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int qt = 0; qt < nfull; ++qt)
+            attn_dkdv_tile<false>(qlds + qt * TILE_BYTES, dolds + qt * TILE_BYTES, stats + qt * 128, kf, vf, dk, dv, c, 64, lane);
+        if (nfull < nqt)
+            attn_dkdv_tile<true>(qlds + nfull * TILE_BYTES, dolds + nfull * TILE_BYTES, stats + nfull * 128, kf, vf, dk, dv, c,
+                                 T - nfull * 64, lane);
+        if (key < T) {
+            __bf16* dst = p.out + ((size_t)b * T + key) * ld + h * HD;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                bf16x4 wk = {f2bf(dk[d][0] * p.scale), f2bf(dk[d][1] * p.scale), f2bf(dk[d][2] * p.scale), f2bf(dk[d][3] * p.scale)};
+                bf16x4 wv = {f2bf(dv[d][0]), f2bf(dv[d][1]), f2bf(dv[d][2]), f2bf(dv[d][3])};
+                *reinterpret_cast<bf16x4*>(dst + D + d * 16 + 4 * g) = wk;
+                *reinterpret_cast<bf16x4*>(dst + 2 * D + d * 16 + 4 * g) = wv;
+            }
+        }
+    }
+}
+
 static int check_attn(const char* fn, int B, int T, int H, int D) {
     P4P_CHECK(B >= 1 && T >= 1 && H >= 1, "%s: bad sizes B=%d T=%d H=%d", fn, B, T, H);
     P4P_CHECK(D == H * HD, "%s: only head_dim 64 is built (D=%d, H=%d)", fn, D, H);
@@ -538,7 +732,11 @@ extern "C" int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B,
     if (check_attn("p4p_attention_fwd", B, T, H, D)) return 1;
     AttnParams p = {};
     p.qkv = (const __bf16*)qkv; p.out = (__bf16*)out; p.lse2 = lse2; p.B = B; p.T = T; p.H = H; p.D = D; p.scale = scale;
-    hipLaunchKernelGGL(attn_fwd_kernel, attn_grid(B, T, H), dim3(ATT_THREADS), 0, (hipStream_t)stream, p);
+    static const bool no_res = getenv("P4P_ATTN_NO_RES") != nullptr;          // A/B switch (tools/ab_bench.sh)
+    if (T <= RES_ROWS - 31 && T >= 64 && !no_res)
+        hipLaunchKernelGGL(attn_fwd_res_kernel, dim3(B * H), dim3(RES_NW * 64), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(attn_fwd_kernel, attn_grid(B, T, H), dim3(ATT_THREADS), 0, (hipStream_t)stream, p);
     P4P_LAUNCH_CHECK();
     return 0;
 }
@@ -560,9 +758,18 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
     AttnParams p = {};
     p.qkv = (const __bf16*)qkv; p.o = (const __bf16*)o; p.dout = (const __bf16*)dout; p.out = (__bf16*)dqkv;
     p.lse2 = (float*)lse2; p.delta = delta; p.colsum = colsum_partial; p.B = B; p.T = T; p.H = H; p.D = D; p.scale = scale;
+    static const bool no_res = getenv("P4P_ATTN_NO_RES") != nullptr;          // A/B switch (tools/ab_bench.sh)
+    static const bool res_dkdv = getenv("P4P_ATTN_RES_DKDV") != nullptr;      // measured slower (128-VGPR cap spills): off
+    const bool res = T <= RES_ROWS - 31 && T >= 64 && !colsum_partial && !no_res;
     dim3 grid = attn_grid(B, T, H);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(ATT_THREADS), 0, st, p);
+    if (res) hipLaunchKernelGGL(attn_bwd_dq_res_kernel, dim3(B * H), dim3(RES_NW * 64), 0, st, p);
+    else hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(ATT_THREADS), 0, st, p);
     P4P_LAUNCH_CHECK();
+    if (res && res_dkdv) {
+        hipLaunchKernelGGL(attn_bwd_dkdv_res_kernel, dim3(B * H), dim3(RES_NW * 64), 0, st, p);
+        P4P_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(ATT_THREADS), 0, st, p);
     P4P_LAUNCH_CHECK();
     return 0;
