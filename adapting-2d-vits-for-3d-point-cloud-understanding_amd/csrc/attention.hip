@@ -603,11 +603,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv_kernel(AttnParam
 // Backward for short sequences (T <= RES_ROWS), same idea as attn_fwd_res_kernel: one workgroup per (b,h), the
 // streamed operand pair resident in LDS, whole 16-row tiles per wave, one barrier in the whole kernel.
 // ------------------------------------------------------------------------------------------------
+template <int NW>
 __device__ __forceinline__ void res_stage_pair(const __bf16* __restrict__ src0, size_t ld0, const __bf16* __restrict__ src1,
                                                size_t ld1, char* lds0, char* lds1, int T, int wave, int lane) {
     const int npieces = ((T + 31) >> 5) * 4;        // whole 32-row contraction steps (rows past T repeat row T-1: finite data)
     const int rin = lane >> 3, chunk = (lane & 7) ^ rin;
-    for (int pc = wave; pc < 2 * npieces; pc += RES_NW) {
+    for (int pc = wave; pc < 2 * npieces; pc += NW) {
         const int second = pc >= npieces, piece = second ? pc - npieces : pc;
         int r = piece * 8 + rin;
         r = r < T ? r : T - 1;
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(RES_NW * 64, 4) void attn_bwd_dq_res_kernel(AttnPar
     const float c = p.scale * 1.4426950408889634f;
     char* klds = lds;
     char* vlds = lds + RES_ROWS * 128;
-    res_stage_pair(seq + D + h * HD, ld, seq + 2 * D + h * HD, ld, klds, vlds, T, wave, lane);
+    res_stage_pair<RES_NW>(seq + D + h * HD, ld, seq + 2 * D + h * HD, ld, klds, vlds, T, wave, lane);
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 
@@ -661,7 +662,8 @@ __global__ __launch_bounds__(RES_NW * 64, 4) void attn_bwd_dq_res_kernel(AttnPar
     }
 }
 
-__global__ __launch_bounds__(RES_NW * 64, 4) void attn_bwd_dkdv_res_kernel(AttnParams p) {
+#define RES_DKDV_NW 4         // 4 waves x ~160 VGPRs (no spills), two workgroups per CU
+__global__ __launch_bounds__(RES_DKDV_NW * 64, 2) void attn_bwd_dkdv_res_kernel(AttnParams p) {
     // Q rows | dO rows | per 64-query tile: lse2[64], delta[64]
     __shared__ __attribute__((aligned(1024))) char lds[2 * RES_ROWS * 128 + (RES_ROWS / 64 + 1) * 512];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
@@ -673,12 +675,12 @@ __global__ __launch_bounds__(RES_NW * 64, 4) void attn_bwd_dkdv_res_kernel(AttnP
     char* qlds = lds;
     char* dolds = lds + RES_ROWS * 128;
     float* stats = reinterpret_cast<float*>(lds + 2 * RES_ROWS * 128);
-    res_stage_pair(seq + h * HD, ld, p.dout + (size_t)b * T * D + h * HD, (size_t)D, qlds, dolds, T, wave, lane);
+    res_stage_pair<RES_DKDV_NW>(seq + h * HD, ld, p.dout + (size_t)b * T * D + h * HD, (size_t)D, qlds, dolds, T, wave, lane);
     const int nqt = (T + 63) / 64, nfull = T / 64;
     {
         const float* lse_b = p.lse2 + ((size_t)b * p.H + h) * T;
         const float* del_b = p.delta + ((size_t)b * p.H + h) * T;
-        for (int e = t; e < nqt * 64; e += RES_NW * 64) {
+        for (int e = t; e < nqt * 64; e += RES_DKDV_NW * 64) {
             const int qq = e < T ? e : T - 1;
             stats[(e >> 6) * 128 + (e & 63)] = lse_b[qq];
             stats[(e >> 6) * 128 + 64 + (e & 63)] = del_b[qq];
@@ -688,8 +690,8 @@ __global__ __launch_bounds__(RES_NW * 64, 4) void attn_bwd_dkdv_res_kernel(AttnP
     __syncthreads();
 
     const int nkt16 = (T + 15) >> 4;
-    const int w0 = (wave + (bh >> 3)) & (RES_NW - 1);
-    for (int kt = w0; kt < nkt16; kt += RES_NW) {
+    const int w0 = (wave + (bh >> 3)) & (RES_DKDV_NW - 1);
+    for (int kt = w0; kt < nkt16; kt += RES_DKDV_NW) {
         const int key = kt * 16 + i;
         const int kc = key < T ? key : T - 1;
         bf16x8 kf[2], vf[2];
@@ -759,14 +761,14 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
     p.qkv = (const __bf16*)qkv; p.o = (const __bf16*)o; p.dout = (const __bf16*)dout; p.out = (__bf16*)dqkv;
     p.lse2 = (float*)lse2; p.delta = delta; p.colsum = colsum_partial; p.B = B; p.T = T; p.H = H; p.D = D; p.scale = scale;
     static const bool no_res = getenv("P4P_ATTN_NO_RES") != nullptr;          // A/B switch (tools/ab_bench.sh)
-    static const bool res_dkdv = getenv("P4P_ATTN_RES_DKDV") != nullptr;      // measured slower (128-VGPR cap spills): off
+    static const bool res_dkdv = getenv("P4P_ATTN_NO_RES_DKDV") == nullptr;   // A/B switch; 4 waves x 220 VGPRs: -0.4 ms/step
     const bool res = T <= RES_ROWS - 31 && T >= 64 && !colsum_partial && !no_res;
     dim3 grid = attn_grid(B, T, H);
     if (res) hipLaunchKernelGGL(attn_bwd_dq_res_kernel, dim3(B * H), dim3(RES_NW * 64), 0, st, p);
     else hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(ATT_THREADS), 0, st, p);
     P4P_LAUNCH_CHECK();
     if (res && res_dkdv) {
-        hipLaunchKernelGGL(attn_bwd_dkdv_res_kernel, dim3(B * H), dim3(RES_NW * 64), 0, st, p);
+        hipLaunchKernelGGL(attn_bwd_dkdv_res_kernel, dim3(B * H), dim3(RES_DKDV_NW * 64), 0, st, p);
         P4P_LAUNCH_CHECK();
         return 0;
     }
