@@ -1,10 +1,10 @@
-// gemm_tn v3: C[M,N] = A[M,K] . W[N,K]^T, block tile 256 x 128, 4 waves each owning 128 x 64,
-// K-step 32, a 3-deep LDS-DMA ring with COUNTED vmcnt and a raw s_barrier, two workgroups per CU.
+// gemm_tn v3: C[M,N] = A[M,K] . W[N,K]^T, block tile 256 x 128 (4 waves, two workgroups per CU) or 256 x 256 (8 waves,
+// one per CU), every wave owning 128 x 64, K-step 32, a 3-deep LDS-DMA ring with COUNTED vmcnt and a raw s_barrier.
+// Since gemm_tn4.h (staggered 4-phase schedule) this is the fallback for shapes that kernel does not take, and the home
+// of the epilogue both share (tile_epilogue_128x64 below).
 //
 // Why this shape (gfx950): the per-wave tile sets the LDS read bytes per MFMA (12 KiB of ds_read_b128 per
-// 32 MFMAs = half of a 64x64 wave tile); 4 waves x ~245 VGPRs and 72 KiB of LDS let TWO workgroups share a
-// CU, so one workgroup's epilogue (HBM-bound: the outputs of these GEMMs are as large as their inputs)
-// overlaps the other's MFMA loop; the block tile keeps L2->LDS traffic at ~47 B/clk/CU at full MFMA rate.
+// 32 MFMAs = half of a 64x64 wave tile); the block tile keeps L2->LDS traffic at ~47 B/clk/CU at full MFMA rate.
 //
 // Pipeline invariant at the top of iteration t: fragments of K-step t are in registers, K-step t+1 has
 // landed in LDS and is barrier-published, K-step t+2 is in flight, ring slot t%3 is free.
@@ -13,9 +13,10 @@
 //     3) 32 MFMAs on K-step t
 //     4) s_waitcnt vmcnt(PPW)  (everything but the PPW loads issued in 1) -> K-step t+2 landed);
 //        s_waitcnt lgkmcnt(0); s_barrier
-// Every load has two full iterations of MFMA time to land; the barrier never drains the load queue.
+// Every load has two full iterations of MFMA time to land; the barrier never drains the load queue.  The ILV variant
+// hand-pins the issue order {1 LDS-DMA, 4 MFMA, 3 fragment reads, 4 MFMA} x 4 inside a step.
 //
-// LDS image per slot: [256 A rows | 128 W rows] x 64 B (32 bf16), 16-B chunk' = chunk ^ (((row>>2)&1)<<1):
+// LDS image per slot: [256 A rows | BN W rows] x 64 B (32 bf16), 16-B chunk' = chunk ^ (((row>>2)&1)<<1):
 // conflict-free for the ds_read_b128 fragment reads (tools/lds_model.py).  LDS-DMA writes lane-linear, so
 // the swizzle is applied to the per-lane SOURCE address.
 #pragma once
