@@ -123,7 +123,8 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
         // Grid quantisation: with few rounds of big tiles (M = 256*257 and N = 768 give 771 tiles of 256x256 on
         // 256 CUs = 3 rounds + 3 tiles -> a 4th round for 0.4% of the work, measured -15..20%), peel the last
         // row tile(s) off and run them with the 128x128 configuration (many small workgroups, one short round).
-        if ((v == 3 || v == 4 || v == 5 || v == 7 || v == 8 || v == 10) && p.M % 256 == 0) {
+        const bool row_remap = EPI == EPI_F32_RESID && p.group > 1;      // token-stream output rows: no peeling / split-K
+        if ((v == 3 || v == 4 || v == 5 || v == 7 || v == 8 || v == 10) && p.M % 256 == 0 && !row_remap) {
             const int bn = (v == 3 || v == 7 || v == 8 || v == 10) ? 256 : T3_BN, slots = (v == 3 || v == 7 || v == 8 || v == 10) ? 256 : 512;
             const int tiles_n = ceil_div(p.N, bn), tiles_m = p.M / 256;
             const long long total = (long long)tiles_m * tiles_n;
@@ -248,7 +249,9 @@ extern "C" int p4p_gemm_tn_bf16(int epi, const void* A, const void* W, void* out
     switch (epi) {
         case EPI_BF16: return launch_tn<EPI_BF16>(p, st);
         case EPI_BF16_GELU: return launch_tn<EPI_BF16_GELU>(p, st);
-        case EPI_F32_RESID: return launch_tn<EPI_F32_RESID>(p, st);
+        case EPI_F32_RESID:
+            P4P_CHECK(group <= 1 || !resid, "p4p_gemm_tn_bf16: EPI_F32_RESID with group > 1 (token-stream rows) takes no residual");
+            return launch_tn<EPI_F32_RESID>(p, st);
         case EPI_BF16_DGELU:
             P4P_CHECK(pre, "p4p_gemm_tn_bf16: EPI_BF16_DGELU needs pre");
             P4P_CHECK(!stats || N % 4 == 0, "p4p_gemm_tn_bf16: column sums need N %% 4 == 0");

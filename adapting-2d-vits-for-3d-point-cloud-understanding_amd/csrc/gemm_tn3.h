@@ -79,9 +79,12 @@ __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 
             }
             const int m = rowbase + j * 16 + li;
             if (m < p.M) {
+                // group = S > 1: token-stream output, row m of the compact [B*S] rows goes to row m + m/S + 1 ([B*(S+1)]
+                // rows, one cls row in front of every sequence: src/models/pix4point.py:248-252 without the torch.cat)
+                const size_t orow = p.group > 1 ? (size_t)m + m / p.group + 1 : (size_t)m;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<f32x4*>(dst + (size_t)m * p.N + i * 16) = (acc[i][j] + bias4[i]) + rcur[i];
+                    *reinterpret_cast<f32x4*>(dst + orow * p.N + i * 16) = (acc[i][j] + bias4[i]) + rcur[i];
             }
         }
         return;

@@ -142,6 +142,55 @@ def linear(x, weight, bias):
     return _LinearFn.apply(x, weight, bias)
 
 
+class _TokenStreamFn(torch.autograd.Function):
+    """stream [B, S+1, N] f32 = cat([cls_vec expanded, Linear(x)], dim=1) (src/models/pix4point.py:245-252) with the
+    GEMM writing the patch rows straight into the stream (no torch.cat), and the backward reading them back as the
+    compact bf16 operand of the dgrad / wgrad GEMMs (no slice copy, no separate cast)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, cls_vec):
+        B, S, K = x.shape
+        N = W.shape[0]
+        x2 = x.reshape(B * S, K)
+        xb = ops.cast_bf16(x2.contiguous()) if x2.dtype == torch.float32 else x2.contiguous()
+        need_t = ctx.needs_input_grad[0]
+        Wb, Wt = _bf16_weights(W, need_t)
+        out = torch.empty(B * (S + 1), N, dtype=torch.float32, device=x.device)
+        ops.gemm_tn(xb, Wb, ops.EPI_F32_RESID, bias=b.detach() if b is not None else None, out=out, group=S)
+        ops.cls_rows_set(out, cls_vec.detach().reshape(N).contiguous(), B, S + 1, N)
+        ctx.save_for_backward(xb, Wt)
+        ctx.dims = (B, S, K, N, b is not None)
+        return out.view(B, S + 1, N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, Wt = ctx.saved_tensors
+        B, S, K, N, has_bias = ctx.dims
+        dy = dy.contiguous()
+        if dy.dtype != torch.float32:
+            dy = dy.float()
+        g = ops.token_rows_to_compact(dy, B, S, N)                      # bf16 [B*S, N]
+        dx = dW = db = dcls = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm_tn(g, Wt, ops.EPI_F32_RESID).view(B, S, K)
+        want_b = has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1]:
+            if want_b:
+                dW, db = ops.gemm_wgrad(g, xb, want_bias=True)
+            else:
+                dW = ops.gemm_wgrad(g, xb)
+        elif want_b:
+            db = ops.colsum(g)
+        if ctx.needs_input_grad[3]:
+            dcls = ops.cls_rows_sum(dy, B, S + 1, N).view(1, 1, N)
+        return dx, dW, db, dcls
+
+
+def token_stream(x, weight, bias, cls_vec):
+    """[B, S, K] -> [B, S+1, N]: cls_vec in row 0 of every sequence, Linear(x) behind it."""
+    return _TokenStreamFn.apply(x, weight, bias, cls_vec)
+
+
 # ================================================================================================
 # ViT encoder: L blocks + final norm
 # ================================================================================================

@@ -80,6 +80,9 @@ def gemm_tn(a, w, epilogue=EPI_BF16, bias=None, resid=None, pre=None, rowgrp=Non
     if w.shape[1] != K:
         raise RuntimeError(f'gemm_tn: a is {tuple(a.shape)}, w is {tuple(w.shape)}')
     f32_out = epilogue == EPI_F32_RESID
+    if f32_out and group > 1:                      # token-stream rows: the caller provides the [B*(S+1), N] buffer
+        if out is None or resid is not None or M % group or out.shape != (M // group * (group + 1), N):
+            raise RuntimeError('gemm_tn: EPI_F32_RESID with group > 1 needs out [M/group*(group+1), N] and no resid')
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32 if f32_out else torch.bfloat16, device=a.device)
     stats = None

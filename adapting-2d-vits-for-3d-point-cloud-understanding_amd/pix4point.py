@@ -7,12 +7,16 @@ pix4point.py:30) and ``grad_sink`` (data-parallel gradient hand-off, the referen
 import math
 from typing import Iterator, List, Optional, Tuple, cast
 
+import os
+
 import torch
 import torch.nn as nn
 
 from . import functional as F
 from . import ops
 from .vit import create_model
+
+_TOKEN_STREAM = os.environ.get('P4P_NO_TOKEN_STREAM') is None     # A/B switch: torch.cat assembly instead
 
 
 def farthest_point_sampling(points: torch.Tensor, n_samples: int,
@@ -107,12 +111,17 @@ class PointViT(nn.Module):
         centers, tok = self.patch_embed.tokens(p, feats_bnc, start_idx)
         p_list = [p, centers]
         x_list = [p.transpose(1, 2) if x is None else x, tok.transpose(1, 2)]
-        xt = F.linear(tok, self.proj.weight, self.proj.bias)                                   # (B,S,D)
         h = torch.nn.functional.gelu(torch.nn.functional.linear(centers, self.pos_embed[0].weight,
                                                                 self.pos_embed[0].bias))
-        pe = F.linear(h, self.pos_embed[2].weight, self.pos_embed[2].bias)
-        pos = torch.cat([self.cls_pos.expand(B, -1, -1), pe], dim=1)
-        feats = torch.cat([self.cls_token.expand(B, -1, -1), xt], dim=1)
+        if _TOKEN_STREAM:
+            # proj / pos_embed[2] write their rows straight into the (B,T,D) streams behind the cls rows (reference :245-252)
+            pos = F.token_stream(h, self.pos_embed[2].weight, self.pos_embed[2].bias, self.cls_pos)
+            feats = F.token_stream(tok, self.proj.weight, self.proj.bias, self.cls_token)
+        else:
+            xt = F.linear(tok, self.proj.weight, self.proj.bias)                               # (B,S,D)
+            pe = F.linear(h, self.pos_embed[2].weight, self.pos_embed[2].bias)
+            pos = torch.cat([self.cls_pos.expand(B, -1, -1), pe], dim=1)
+            feats = torch.cat([self.cls_token.expand(B, -1, -1), xt], dim=1)
         feats = F.encoder(feats, pos, list(self.vit_blocks), self.norm, self.vit.num_heads, self.grad_sink)
         return p_list, x_list, feats
 
