@@ -98,18 +98,63 @@ __global__ void token_rows_kernel(float* __restrict__ stream, void* __restrict__
     }
 }
 
-// cls rows: mode 1: stream[b*T] = vec;  mode 0: out[c] = sum_b stream[b*T][c]
-__global__ void cls_rows_kernel(float* __restrict__ stream, float* __restrict__ vec, int B, int T, int D, int mode) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= D) return;
+// cls rows: mode 1: stream[b*T] = vec;  mode 0: out[c] = sum_b stream[b*T][c]  (256 threads = 64 columns x 4 b-lanes,
+// fixed order: reproducible)
+__global__ __launch_bounds__(256) void cls_rows_kernel(float* __restrict__ stream, float* __restrict__ vec, int B, int T, int D,
+                                                       int mode) {
     if (mode == 1) {
+        const int c = blockIdx.x * 256 + threadIdx.x;
+        if (c >= D) return;
         const float v = vec[c];
         for (int b = blockIdx.y; b < B; b += gridDim.y) stream[(size_t)b * T * D + c] = v;
-    } else {
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) s += stream[(size_t)b * T * D + c];
-        vec[c] = s;
+        return;
     }
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float s = 0.f;
+    if (c < D)
+        for (int b = ty; b < B; b += 4) s += stream[(size_t)b * T * D + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < D) vec[c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
+// Global feature of PointViT.forward_cls_feat (src/models/pix4point.py:260-271): max over the patch tokens x[:,1:] and
+// the cls token x[:,0].  fwd: out_max[b][c], arg[b][c] (token index of the first maximum), out_cls[b][c].
+// bwd: dx[b][t][c] = dmax[b][c] at t = arg (+ dcls[b][c] at t = 0), zero elsewhere -- ONE pass over dx instead of
+// torch's zeros + scatter + slice-pad + add.
+__global__ __launch_bounds__(256) void global_feat_fwd_kernel(const float* __restrict__ x, float* __restrict__ out_max,
+                                                              int* __restrict__ arg, float* __restrict__ out_cls, int T, int D) {
+    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (c >= D) return;
+    const float* xb = x + (size_t)b * T * D + c;
+    if (out_cls) out_cls[(size_t)b * D + c] = xb[0];
+    if (out_max) {
+        float m = -INFINITY;
+        int am = 1;
+        for (int t = 1; t < T; ++t) {
+            const float v = xb[(size_t)t * D];
+            if (v > m || v != v) { if (!(m != m)) { m = v; am = t; } }      // first maximum; a NaN wins and stays (torch.max)
+        }
+        out_max[(size_t)b * D + c] = m;
+        arg[(size_t)b * D + c] = am;
+    }
+}
+__global__ __launch_bounds__(256) void global_feat_bwd_kernel(float* __restrict__ dx, const float* __restrict__ dmax,
+                                                              const int* __restrict__ arg, const float* __restrict__ dcls,
+                                                              int T, int D) {
+    const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4, t = blockIdx.y, b = blockIdx.z;
+    if (c4 >= D) return;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const size_t bd = (size_t)b * D + c4;
+    if (dmax) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (arg[bd + r] == t) v[r] = dmax[bd + r];
+    }
+    if (dcls && t == 0) v += *reinterpret_cast<const f32x4*>(dcls + bd);
+    *reinterpret_cast<f32x4*>(dx + ((size_t)b * T + t) * D + c4) = v;
 }
 
 extern "C" int p4p_cast_transpose_f32_bf16(const float* src, long long ld_src, void* dst, void* dstT, int R, int C,
@@ -175,8 +220,26 @@ extern "C" int p4p_token_rows(float* stream_f32, void* compact, int B, int S, in
 
 extern "C" int p4p_cls_rows(float* stream_f32, float* vec, int B, int T, int D, int mode, void* stream) {
     P4P_CHECK(stream_f32 && vec && B >= 1 && T >= 1 && D >= 1 && (mode == 0 || mode == 1), "p4p_cls_rows: bad arguments");
-    dim3 grid(ceil_div(D, 256), mode == 1 ? (B < 64 ? B : 64) : 1);
+    dim3 grid(mode == 1 ? ceil_div(D, 256) : ceil_div(D, 64), mode == 1 ? (B < 64 ? B : 64) : 1);
     hipLaunchKernelGGL(cls_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, stream_f32, vec, B, T, D, mode);
+    P4P_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int p4p_global_feat_fwd(const float* x, float* out_max, int* arg, float* out_cls, int B, int T, int D, void* stream) {
+    P4P_CHECK(x && (out_cls || (out_max && arg)) && B >= 1 && T >= 2 && D >= 1 && B <= 65535, "p4p_global_feat_fwd: bad arguments");
+    hipLaunchKernelGGL(global_feat_fwd_kernel, dim3(ceil_div(D, 256), B), dim3(256), 0, (hipStream_t)stream, x, out_max, arg,
+                       out_cls, T, D);
+    P4P_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int p4p_global_feat_bwd(float* dx, const float* dmax, const int* arg, const float* dcls, int B, int T, int D,
+                                   void* stream) {
+    P4P_CHECK(dx && (!dmax || arg) && B >= 1 && T >= 2 && D >= 4 && D % 4 == 0 && B <= 65535 && T <= 65535,
+              "p4p_global_feat_bwd: bad arguments");
+    hipLaunchKernelGGL(global_feat_bwd_kernel, dim3(ceil_div(D / 4, 256), T, B), dim3(256), 0, (hipStream_t)stream, dx, dmax, arg,
+                       dcls, T, D);
     P4P_LAUNCH_CHECK();
     return 0;
 }

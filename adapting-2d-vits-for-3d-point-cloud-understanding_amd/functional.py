@@ -186,6 +186,39 @@ class _TokenStreamFn(torch.autograd.Function):
         return dx, dW, db, dcls
 
 
+class _GlobalFeatFn(torch.autograd.Function):
+    """cat of {max over patch tokens x[:,1:], cls token x[:,0]} in the given order (src/models/pix4point.py:260-271); the
+    backward writes dx in one pass instead of torch's zeros + scatter + slice-pad + add over (B,T,D)."""
+
+    @staticmethod
+    def forward(ctx, x, kinds):
+        x = x.contiguous()
+        B, T, D = x.shape
+        mx, arg, cls = ops.global_feat_fwd(x, 'max' in kinds, 'cls' in kinds)
+        ctx.kinds, ctx.dims = kinds, (B, T, D)
+        ctx.save_for_backward(arg if arg is not None else x.new_empty(0, dtype=torch.int32))
+        return torch.cat([mx if k == 'max' else cls for k in kinds], dim=1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        B, T, D = ctx.dims
+        dy = dy.contiguous().float()
+        dmax = dcls = None
+        for j, k in enumerate(ctx.kinds):
+            piece = dy[:, j * D:(j + 1) * D].contiguous()
+            if k == 'max':
+                dmax = piece
+            else:
+                dcls = piece
+        return ops.global_feat_bwd(dmax, arg if dmax is not None else None, dcls, B, T, D, dy.device), None
+
+
+def global_feat(x, kinds):
+    """kinds: tuple of 'max' / 'cls' (one of each at most), in output order."""
+    return _GlobalFeatFn.apply(x, tuple(kinds))
+
+
 def token_stream(x, weight, bias, cls_vec):
     """[B, S, K] -> [B, S+1, N]: cls_vec in row 0 of every sequence, Linear(x) behind it."""
     return _TokenStreamFn.apply(x, weight, bias, cls_vec)

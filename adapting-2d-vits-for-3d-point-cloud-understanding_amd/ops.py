@@ -275,6 +275,22 @@ def cls_rows_sum(stream, B, T, D):
     return out
 
 
+def global_feat_fwd(x, want_max, want_cls):
+    _chk(x, 'x', torch.float32, 3)
+    B, T, D = x.shape
+    mx = torch.empty(B, D, dtype=torch.float32, device=x.device) if want_max else None
+    arg = torch.empty(B, D, dtype=torch.int32, device=x.device) if want_max else None
+    cls = torch.empty(B, D, dtype=torch.float32, device=x.device) if want_cls else None
+    L.call('p4p_global_feat_fwd', L.ptr(x), L.ptr(mx), L.ptr(arg), L.ptr(cls), B, T, D, _stream())
+    return mx, arg, cls
+
+
+def global_feat_bwd(dmax, arg, dcls, B, T, D, device):
+    dx = torch.empty(B, T, D, dtype=torch.float32, device=device)
+    L.call('p4p_global_feat_bwd', L.ptr(dx), L.ptr(dmax), L.ptr(arg), L.ptr(dcls), B, T, D, _stream())
+    return dx
+
+
 def colreduce(part, nrows, ncols):
     out = torch.empty(ncols, dtype=torch.float32, device=part.device)
     L.call('p4p_colreduce_f32', L.ptr(part), L.ptr(out), int(nrows), L.i64(ncols), int(ncols), 0.0, _stream())

@@ -128,6 +128,14 @@ class PointViT(nn.Module):
     def forward_cls_feat(self, p: torch.Tensor, x: Optional[torch.Tensor] = None,
                          start_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
         _, _, x = self.forward(p, x, start_idx)
+        kinds = []
+        for token_type in self.global_features:
+            if 'cls' in token_type:
+                kinds.append('cls')
+            if 'max' in token_type:
+                kinds.append('max')
+        if _TOKEN_STREAM and kinds and len(set(kinds)) == len(kinds) and x.dtype == torch.float32:
+            return F.global_feat(x, kinds)             # one kernel each way (functional._GlobalFeatFn)
         token_features = x[:, 1:, :]
         cls_feats = []
         for token_type in self.global_features:

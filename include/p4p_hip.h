@@ -160,6 +160,12 @@ int p4p_prof_collect(double* out);
 int p4p_set_gemm_variant(int v);
 int p4p_set_wgrad_wide(int v);
 
+/* ---- global feature of PointViT.forward_cls_feat (src/models/pix4point.py:260-271) ----
+   fwd: out_max[B,D] = max over tokens 1..T-1 of x[B,T,D] (arg[B,D] = token index of the first maximum), out_cls[B,D] = x[:,0]
+   (either output may be NULL); bwd: dx[B,T,D] written in one pass (dmax scattered to arg, dcls to token 0, zero elsewhere). */
+int p4p_global_feat_fwd(const float* x, float* out_max, int* arg, float* out_cls, int B, int T, int D, void* stream);
+int p4p_global_feat_bwd(float* dx, const float* dmax, const int* arg, const float* dcls, int B, int T, int D, void* stream);
+
 /* ---- train-step tail: clip_grad_norm_ + AdamW over all parameter tensors (src/train/pix4point_trainer.py:164-167) ----
    tensors: device array of {float* p; const float* g; float* m; float* v; long long n; float lr, wd} (48 B each);
    chunks: device array of {int tensor; int offset} in units of p4p_opt_chunk_elems() elements, never straddling tensors. */

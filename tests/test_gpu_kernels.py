@@ -396,3 +396,21 @@ def test_gemm_wgrad_ring_kernel_exact_on_integer_data(M, N, K):
     assert torch.equal(db, g.float().sum(0))
     acc = ops.gemm_wgrad(g, a, out=dw.clone(), beta=1.0)
     assert torch.equal(acc, 2 * want)
+
+
+def test_global_feat_matches_torch():
+    """max over patch tokens + cls token (src/models/pix4point.py:260-271) and their gradient, against torch."""
+    from p4p_amd import functional as F
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(5, 33, 64, generator=g).to(DEV)
+    x[0, 7, 3] = x[0, 9, 3] = 9.0                              # a tie: the first maximum takes the gradient (torch.max)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    got = F.global_feat(xa, ('max', 'cls'))
+    want = torch.cat([xb[:, 1:, :].max(dim=1)[0], xb[:, 0, :]], dim=1)
+    assert torch.equal(got, want)
+    w = torch.randn(5, 128, generator=g).to(DEV)
+    (got * w).sum().backward()
+    (want * w).sum().backward()
+    assert torch.equal(xa.grad, xb.grad)
+    got2 = F.global_feat(x, ('cls', 'max'))
+    assert torch.equal(got2, torch.cat([x[:, 0, :], x[:, 1:, :].max(dim=1)[0]], dim=1))
