@@ -4,6 +4,7 @@
 //   * row remaps between the token stream [B*T,D] (cls row first, src/models/pix4point.py:248-252)
 //     and the compact patch rows [B*S,D].
 #include "common.h"
+#include "gemm_tn.h"        // gelu_f / dgelu_f (exact-erf GELU)
 
 // dst[r][c] = bf16(src[r*ld + c]);  dstT[c][r] = same.  32x32 tiles through LDS.
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, long long ld,
@@ -222,6 +223,67 @@ extern "C" int p4p_cls_rows(float* stream_f32, float* vec, int B, int T, int D, 
     P4P_CHECK(stream_f32 && vec && B >= 1 && T >= 1 && D >= 1 && (mode == 0 || mode == 1), "p4p_cls_rows: bad arguments");
     dim3 grid(mode == 1 ? ceil_div(D, 256) : ceil_div(D, 64), mode == 1 ? (B < 64 ? B : 64) : 1);
     hipLaunchKernelGGL(cls_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, stream_f32, vec, B, T, D, mode);
+    P4P_LAUNCH_CHECK();
+    return 0;
+}
+
+// First layer of PointViT.pos_embed (src/models/pix4point.py:214-218,246): h = GELU(Linear(3, C)(centers)).  K = 3 is no
+// GEMM: one thread per output (fwd), and in the backward the C x 3 weight gradient is a reduction over the rows that
+// rocBLAS runs with a 16x32 macro-tile in ~0.2 ms; here every workgroup reduces 256 rows into partial[blk][C][4]
+// (dW[j][0..2], db[j]) and p4p_colreduce_f32 finishes (fixed order).  The input gets no gradient (points are data).
+__global__ __launch_bounds__(256) void pos_mlp0_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                           const float* __restrict__ b, void* __restrict__ h, int h_bf16,
+                                                           long long M, int C) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= M * C) return;
+    const long long m = e / C;
+    const int j = (int)(e - m * C);
+    const float pre = (x[m * 3] * W[j * 3] + x[m * 3 + 1] * W[j * 3 + 1]) + (x[m * 3 + 2] * W[j * 3 + 2] + b[j]);
+    const float y = gelu_f(pre);
+    if (h_bf16) ((__bf16*)h)[e] = f2bf(y);
+    else ((float*)h)[e] = y;
+}
+#define POS0_ROWS 256
+__global__ __launch_bounds__(256) void pos_mlp0_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                           const float* __restrict__ b, const float* __restrict__ dh,
+                                                           float* __restrict__ partial, long long M, int C) {
+    // thread = (column j = tid % C, row lane = tid / C); C divides 256
+    const int j = threadIdx.x % C, rl = threadIdx.x / C, nrl = 256 / C;
+    const long long m0 = (long long)blockIdx.x * POS0_ROWS;
+    const float w0 = W[j * 3], w1 = W[j * 3 + 1], w2 = W[j * 3 + 2], bj = b[j];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, ab = 0.f;
+    for (int r = rl; r < POS0_ROWS; r += nrl) {
+        const long long m = m0 + r;
+        if (m >= M) break;
+        const float x0 = x[m * 3], x1 = x[m * 3 + 1], x2 = x[m * 3 + 2];
+        const float pre = (x0 * w0 + x1 * w1) + (x2 * w2 + bj);
+        const float g = dh[m * C + j] * dgelu_f(pre);
+        a0 += g * x0; a1 += g * x1; a2 += g * x2; ab += g;
+    }
+    __shared__ f32x4 red[256];
+    red[threadIdx.x] = f32x4{a0, a1, a2, ab};
+    __syncthreads();
+    if (rl == 0) {
+        f32x4 s = red[j];
+        for (int q = 1; q < nrl; ++q) s += red[q * C + j];
+        *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * C + j) * 4) = s;
+    }
+}
+
+extern "C" int p4p_pos_mlp0_fwd(const float* x, const float* W, const float* b, void* h, int h_is_bf16, long long M, int C,
+                                void* stream) {
+    P4P_CHECK(x && W && b && h && M >= 1 && C >= 1, "p4p_pos_mlp0_fwd: bad arguments");
+    hipLaunchKernelGGL(pos_mlp0_fwd_kernel, dim3(ceil_div(M * C, 256)), dim3(256), 0, (hipStream_t)stream, x, W, b, h, h_is_bf16, M, C);
+    P4P_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int p4p_pos_mlp0_bwd_rows(long long M) { return ceil_div(M, POS0_ROWS); }
+// partial: [p4p_pos_mlp0_bwd_rows(M)][C][4] floats; column sums over the first dimension = (dW[j][0..2], db[j])
+extern "C" int p4p_pos_mlp0_bwd(const float* x, const float* W, const float* b, const float* dh, float* partial, long long M,
+                                int C, void* stream) {
+    P4P_CHECK(x && W && b && dh && partial && M >= 1, "p4p_pos_mlp0_bwd: bad arguments");
+    P4P_CHECK(C >= 1 && C <= 256 && 256 % C == 0, "p4p_pos_mlp0_bwd: C=%d must divide 256", C);
+    hipLaunchKernelGGL(pos_mlp0_bwd_kernel, dim3(ceil_div(M, POS0_ROWS)), dim3(256), 0, (hipStream_t)stream, x, W, b, dh, partial, M, C);
     P4P_LAUNCH_CHECK();
     return 0;
 }

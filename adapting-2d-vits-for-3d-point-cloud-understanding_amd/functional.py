@@ -186,6 +186,27 @@ class _TokenStreamFn(torch.autograd.Function):
         return dx, dW, db, dcls
 
 
+class _PosMlp0Fn(torch.autograd.Function):
+    """GELU(Linear(3, C)(centers)): first layer of PointViT.pos_embed (src/models/pix4point.py:214-218,246)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        x2 = x.reshape(-1, 3).contiguous().float()
+        Wd, bd = W.detach().contiguous(), b.detach().contiguous()
+        ctx.save_for_backward(x2, Wd, bd)
+        return ops.pos_mlp0_fwd(x2, Wd, bd).view(*x.shape[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, dh):
+        x2, Wd, bd = ctx.saved_tensors
+        dW, db = ops.pos_mlp0_bwd(x2, Wd, bd, dh.reshape(-1, dh.shape[-1]).contiguous().float())
+        return None, dW, db
+
+
+def pos_mlp0(x, weight, bias):
+    return _PosMlp0Fn.apply(x, weight, bias)
+
+
 class _GlobalFeatFn(torch.autograd.Function):
     """cat of {max over patch tokens x[:,1:], cls token x[:,0]} in the given order (src/models/pix4point.py:260-271); the
     backward writes dx in one pass instead of torch's zeros + scatter + slice-pad + add over (B,T,D)."""

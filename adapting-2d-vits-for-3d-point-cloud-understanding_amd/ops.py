@@ -275,6 +275,25 @@ def cls_rows_sum(stream, B, T, D):
     return out
 
 
+def pos_mlp0_fwd(x, W, b):
+    """GELU(x[M,3] @ W[C,3]^T + b) -> f32 [M, C]."""
+    _chk(x, 'x', torch.float32, 2)
+    M, C = x.shape[0], W.shape[0]
+    h = torch.empty(M, C, dtype=torch.float32, device=x.device)
+    L.call('p4p_pos_mlp0_fwd', L.ptr(x), L.ptr(W), L.ptr(b), L.ptr(h), 0, L.i64(M), C, _stream())
+    return h
+
+
+def pos_mlp0_bwd(x, W, b, dh):
+    """-> (dW [C,3], db [C])."""
+    M, C = x.shape[0], W.shape[0]
+    rows = L.call_int('p4p_pos_mlp0_bwd_rows', L.i64(M))
+    part = _workspace('pos0', rows * C * 4, x.device)
+    L.call('p4p_pos_mlp0_bwd', L.ptr(x), L.ptr(W), L.ptr(b), L.ptr(dh), L.ptr(part), L.i64(M), C, _stream())
+    s = colreduce(part, rows, C * 4).view(C, 4)
+    return s[:, :3].contiguous(), s[:, 3].contiguous()
+
+
 def global_feat_fwd(x, want_max, want_cls):
     _chk(x, 'x', torch.float32, 3)
     B, T, D = x.shape

@@ -111,8 +111,11 @@ class PointViT(nn.Module):
         centers, tok = self.patch_embed.tokens(p, feats_bnc, start_idx)
         p_list = [p, centers]
         x_list = [p.transpose(1, 2) if x is None else x, tok.transpose(1, 2)]
-        h = torch.nn.functional.gelu(torch.nn.functional.linear(centers, self.pos_embed[0].weight,
-                                                                self.pos_embed[0].bias))
+        if _TOKEN_STREAM and 256 % self.pos_embed[0].weight.shape[0] == 0:
+            h = F.pos_mlp0(centers, self.pos_embed[0].weight, self.pos_embed[0].bias)      # K = 3: not a GEMM
+        else:
+            h = torch.nn.functional.gelu(torch.nn.functional.linear(centers, self.pos_embed[0].weight,
+                                                                    self.pos_embed[0].bias))
         if _TOKEN_STREAM:
             # proj / pos_embed[2] write their rows straight into the (B,T,D) streams behind the cls rows (reference :245-252)
             pos = F.token_stream(h, self.pos_embed[2].weight, self.pos_embed[2].bias, self.cls_pos)

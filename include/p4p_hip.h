@@ -166,6 +166,13 @@ int p4p_set_wgrad_wide(int v);
 int p4p_global_feat_fwd(const float* x, float* out_max, int* arg, float* out_cls, int B, int T, int D, void* stream);
 int p4p_global_feat_bwd(float* dx, const float* dmax, const int* arg, const float* dcls, int B, int T, int D, void* stream);
 
+/* ---- first layer of PointViT.pos_embed: h[M,C] = GELU(x[M,3] W[C,3]^T + b)  (src/models/pix4point.py:214-218,246) ----
+   bwd: partial [p4p_pos_mlp0_bwd_rows(M)][C][4] f32; its column sums (p4p_colreduce_f32) are (dW[j][0..2], db[j]). */
+int p4p_pos_mlp0_fwd(const float* x, const float* W, const float* b, void* h, int h_is_bf16, long long M, int C, void* stream);
+int p4p_pos_mlp0_bwd_rows(long long M);
+int p4p_pos_mlp0_bwd(const float* x, const float* W, const float* b, const float* dh, float* partial, long long M, int C,
+                     void* stream);
+
 /* ---- train-step tail: clip_grad_norm_ + AdamW over all parameter tensors (src/train/pix4point_trainer.py:164-167) ----
    tensors: device array of {float* p; const float* g; float* m; float* v; long long n; float lr, wd} (48 B each);
    chunks: device array of {int tensor; int offset} in units of p4p_opt_chunk_elems() elements, never straddling tensors. */

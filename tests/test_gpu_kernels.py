@@ -414,3 +414,20 @@ def test_global_feat_matches_torch():
     assert torch.equal(xa.grad, xb.grad)
     got2 = F.global_feat(x, ('cls', 'max'))
     assert torch.equal(got2, torch.cat([x[:, 0, :], x[:, 1:, :].max(dim=1)[0]], dim=1))
+
+
+def test_pos_mlp0_matches_torch():
+    """GELU(Linear(3,128)) of PointViT.pos_embed and its weight / bias gradients against torch (fp32)."""
+    from p4p_amd import functional as F
+    g = torch.Generator().manual_seed(6)
+    x = (torch.rand(3, 700, 3, generator=g) * 2 - 1).to(DEV)
+    lin_a, lin_b = torch.nn.Linear(3, 128).to(DEV), torch.nn.Linear(3, 128).to(DEV)
+    lin_b.load_state_dict(lin_a.state_dict())
+    got = F.pos_mlp0(x, lin_a.weight, lin_a.bias)
+    want = torch.nn.functional.gelu(lin_b(x))
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=2e-6)
+    w = torch.randn(3, 700, 128, generator=g).to(DEV)
+    (got * w).sum().backward()
+    (want * w).sum().backward()
+    torch.testing.assert_close(lin_a.weight.grad, lin_b.weight.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(lin_a.bias.grad, lin_b.bias.grad, rtol=1e-4, atol=1e-3)
