@@ -444,9 +444,14 @@ __global__ __launch_bounds__(256) void embed_stage1_bwd_kernel(const float* __re
                                                                const uint8_t* __restrict__ arg,
                                                                float* __restrict__ partial, long long G, int N, int S,
                                                                int k, int C1) {
+    // thread = (channel quad cq = tid & 63, position lane pl = tid >> 6): 8-B loads of F1 / dF1 and 4 independent position
+    // streams per channel instead of one 2-B load per lane and iteration (the kernel ran at 1.9 TB/s, latency-bound)
     extern __shared__ float xs[];
-    const int c = threadIdx.x;
-    float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int cq = threadIdx.x & 63, pl = threadIdx.x >> 6, c4 = cq * 4;
+    const bool cok = c4 < C1;                                   // C1 % 4 == 0 (checked by the launcher)
+    f32x4 acc[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int SK = S * k;
     for (long long g0 = (long long)blockIdx.x * GPB; g0 < G; g0 += (long long)gridDim.x * GPB) {
         const int ng = (int)((G - g0) < GPB ? (G - g0) : GPB);
@@ -458,15 +463,21 @@ __global__ __launch_bounds__(256) void embed_stage1_bwd_kernel(const float* __re
             for (int d = 0; d < X6; ++d) xs[i * 8 + d] = x[d];
         }
         __syncthreads();
-        if (c < C1) {
+        if (cok) {
             for (int g = 0; g < ng; ++g) {
-                const float dp = bf2f(dPooled[(size_t)(g0 + g) * C1 + c]);
-                const int am = arg[(size_t)(g0 + g) * C1 + c];
-                for (int j = 0; j < k; ++j) {
-                    const size_t o = ((size_t)(g0 + g) * k + j) * C1 + c;
-                    float dy = bf2f(dF1[o]) + (j == am ? dp : 0.f);
-                    dy = bf2f(F1[o]) > 0.f ? dy : 0.f;
+                const bf16x4 dp = *reinterpret_cast<const bf16x4*>(dPooled + (size_t)(g0 + g) * C1 + c4);
+                const u32 am4 = *reinterpret_cast<const u32*>(arg + (size_t)(g0 + g) * C1 + c4);
+                for (int j = pl; j < k; j += 4) {
+                    const size_t o = ((size_t)(g0 + g) * k + j) * C1 + c4;
+                    const bf16x4 d4 = *reinterpret_cast<const bf16x4*>(dF1 + o);
+                    const bf16x4 f4 = *reinterpret_cast<const bf16x4*>(F1 + o);
                     const float* x = xs + (g * k + j) * 8;
+                    f32x4 dy;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = bf2f(d4[r]) + (j == (int)((am4 >> (8 * r)) & 255u) ? bf2f(dp[r]) : 0.f);
+                        dy[r] = bf2f(f4[r]) > 0.f ? v : 0.f;
+                    }
                     acc[0] += dy;
 #pragma unroll
                     for (int d = 0; d < X6; ++d) acc[1 + d] += dy * x[d];
@@ -474,9 +485,18 @@ __global__ __launch_bounds__(256) void embed_stage1_bwd_kernel(const float* __re
             }
         }
     }
-    if (c < C1) {
+    // the four position lanes of a channel quad -> one partial row set (fixed order)
+    __syncthreads();
+    f32x4* red = reinterpret_cast<f32x4*>(xs);                   // >= 256 * 7 * 16 B = 28 KiB (see the launcher)
 #pragma unroll
-        for (int q = 0; q < 7; ++q) partial[((size_t)blockIdx.x * 7 + q) * C1 + c] = acc[q];
+    for (int q = 0; q < 7; ++q) red[(q * 4 + pl) * 64 + cq] = acc[q];
+    __syncthreads();
+    if (pl == 0 && cok) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const f32x4 s = (red[(q * 4 + 0) * 64 + cq] + red[(q * 4 + 1) * 64 + cq]) + (red[(q * 4 + 2) * 64 + cq] + red[(q * 4 + 3) * 64 + cq]);
+            *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 7 + q) * C1 + c4) = s;
+        }
     }
 }
 
@@ -689,7 +709,10 @@ extern "C" int p4p_embed_stage1_bwd(const float* points, const float* feats, con
     long long G = (long long)B * S;
     int blocks = (int)((G + GPB - 1) / GPB);
     if (blocks > EMBED_BLOCKS) blocks = EMBED_BLOCKS;
-    hipLaunchKernelGGL(embed_stage1_bwd_kernel, dim3(blocks), dim3(256), GPB * k * 8 * sizeof(float), st, points, feats,
+    P4P_CHECK(C1 % 4 == 0, "p4p_embed_stage1_bwd: C1=%d must be a multiple of 4", C1);
+    size_t shm = (size_t)GPB * k * 8 * sizeof(float);
+    if (shm < 7 * 4 * 64 * 16) shm = 7 * 4 * 64 * 16;               // the cross-lane reduction reuses the coordinate buffer
+    hipLaunchKernelGGL(embed_stage1_bwd_kernel, dim3(blocks), dim3(256), shm, st, points, feats,
                        idx, (const __bf16*)F1, (const __bf16*)dF1, (const __bf16*)dPooled, arg, partial, G, N, S, k, C1);
     P4P_LAUNCH_CHECK();
     if (p4p_colreduce_f32(partial, sums, blocks, (long long)7 * C1, 7 * C1, 0.f, stream)) return 2;

@@ -8,7 +8,7 @@ g = torch.Generator().manual_seed(0)
 a = torch.randn(M, 4 * D, generator=g).to(torch.bfloat16).cuda()
 w = (torch.randn(D, 4 * D, generator=g) * 0.02).to(torch.bfloat16).cuda()
 out = torch.empty(M, D, dtype=torch.bfloat16, device='cuda')
-for v in (3, 7, 4):
+for v in (8, 10):
     lib.p4p_set_gemm_variant(v)
     for _ in range(3):
         ops.gemm_tn(a, w, ops.EPI_BF16, out=out)
