@@ -182,6 +182,44 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
     }
 }
 
+// Same reduction with 16-B loads: 256 threads = 4 column quads x 64 row lanes (16 rows per lane at 1024 partial rows, four
+// independent loads in flight per lane).  The scalar kernel above walks 64 rows per lane two at a time and takes its
+// ~16 us from that dependent-latency chain, not from the 9 MB it reads.
+__global__ __launch_bounds__(256) void colreduce4_kernel(const float* __restrict__ part, float* __restrict__ out, int nrows,
+                                                          long long stride, int ncols, float beta) {
+    __shared__ f32x4 red[64][4];
+    const int tx = threadIdx.x & 3, ty = threadIdx.x >> 2;
+    const int c = (blockIdx.x * 4 + tx) * 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (c < ncols) {
+        const float* p0 = part + c;
+        int r = ty;
+        for (; r + 192 < nrows; r += 256) {
+            s0 += *reinterpret_cast<const f32x4*>(p0 + (size_t)r * stride);
+            s1 += *reinterpret_cast<const f32x4*>(p0 + (size_t)(r + 64) * stride);
+            s2 += *reinterpret_cast<const f32x4*>(p0 + (size_t)(r + 128) * stride);
+            s3 += *reinterpret_cast<const f32x4*>(p0 + (size_t)(r + 192) * stride);
+        }
+        for (; r < nrows; r += 64) s0 += *reinterpret_cast<const f32x4*>(p0 + (size_t)r * stride);
+    }
+    red[ty][tx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    for (int h = 32; h >= 1; h >>= 1) {
+        if (ty < h) red[ty][tx] += red[ty + h][tx];
+        __syncthreads();
+    }
+    if (ty == 0 && c < ncols) {
+        f32x4 v = red[0][tx];
+        if (beta != 0.f) v += beta * *reinterpret_cast<const f32x4*>(out + c);
+        *reinterpret_cast<f32x4*>(out + c) = v;
+    }
+}
+static void launch_colreduce(const float* part, float* out, int nrows, long long stride, int ncols, float beta, hipStream_t st) {
+    const bool vec = ncols % 4 == 0 && stride % 4 == 0 && ((reinterpret_cast<size_t>(part) | reinterpret_cast<size_t>(out)) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(colreduce4_kernel, dim3(ceil_div(ncols, 16)), dim3(256), 0, st, part, out, nrows, stride, ncols, beta);
+    else hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(ncols, 16)), dim3(256), 0, st, part, out, nrows, stride, ncols, beta);
+}
+
 #define LN_BWD_BLOCKS 1024
 
 extern "C" int p4p_layernorm_bwd_partial_rows(void) { return LN_BWD_BLOCKS; }
@@ -222,16 +260,14 @@ extern "C" int p4p_layernorm_bwd(const void* dy, int dy_is_f32, const float* xin
     P4P_LAUNCH_CHECK();
     if (dgamma && dbeta == dgamma + D && (!dxsum || dxsum == dgamma + 2 * D)) {   // contiguous destination: one launch
         const int rows = dxsum ? 3 : 2;
-        hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(rows * D, 16)), dim3(256), 0, st, partial, dgamma, blocks,
-                           (long long)3 * D, rows * D, beta_acc);
+        launch_colreduce(partial, dgamma, blocks, (long long)3 * D, rows * D, beta_acc, st);
         P4P_LAUNCH_CHECK();
         return 0;
     }
     float* dst[3] = {dgamma, dbeta, dxsum};
     for (int i = 0; i < 3; ++i) {
         if (!dst[i]) continue;
-        hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(D, 16)), dim3(256), 0, st, partial + (size_t)i * D, dst[i],
-                           blocks, (long long)3 * D, D, beta_acc);
+        launch_colreduce(partial + (size_t)i * D, dst[i], blocks, (long long)3 * D, D, beta_acc, st);
         P4P_LAUNCH_CHECK();
     }
     return 0;
@@ -240,8 +276,7 @@ extern "C" int p4p_layernorm_bwd(const void* dy, int dy_is_f32, const float* xin
 extern "C" int p4p_colreduce_f32(const float* part, float* out, int nrows, long long stride, int ncols, float beta,
                                  void* stream) {
     P4P_CHECK(part && out && nrows >= 1 && ncols >= 1, "p4p_colreduce_f32: bad arguments");
-    hipLaunchKernelGGL(colreduce_kernel, dim3(ceil_div(ncols, 16)), dim3(256), 0, (hipStream_t)stream, part, out,
-                       nrows, stride, ncols, beta);
+    launch_colreduce(part, out, nrows, stride, ncols, beta, (hipStream_t)stream);
     P4P_LAUNCH_CHECK();
     return 0;
 }
