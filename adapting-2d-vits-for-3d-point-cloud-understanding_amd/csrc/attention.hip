@@ -111,6 +111,7 @@ __device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
 // dqkv; the rows are in registers here, so the backward kernels emit partial sums instead of a separate pass
 // re-reading the 300-MB dqkv.  The bf16-ROUNDED values are summed: the result equals a column sum of the stored
 // tensor up to summation order (which is fixed: reproducible).
+template <bool ROUND = true>     // ROUND: x holds unrounded gradients (sum what is stored); false: x already is a sum of rounded values
 __device__ __forceinline__ void wave_colsum(const f32x4 (&x)[4], bool valid, float* dst, int lane) {
     // Transposing butterfly over the 16 lanes of a row: at every step a lane keeps the half of its values whose
     // column-index bit matches its own lane bit and adds the partner's copy of them (xor masks 8, 7, 2, 1 = the DPP
@@ -122,7 +123,7 @@ __device__ __forceinline__ void wave_colsum(const f32x4 (&x)[4], bool valid, flo
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[d * 4 + r] = valid ? bf2f(f2bf(x[d][r])) : 0.f;
+        for (int r = 0; r < 4; ++r) v[d * 4 + r] = valid ? (ROUND ? bf2f(f2bf(x[d][r])) : x[d][r]) : 0.f;
     float w8[8], w4[4], w2[2];
 #pragma unroll
     for (int c = 0; c < 8; ++c) w8[c] = (b3 ? v[c + 8] : v[c]) + dpp_f32<0x128>(b3 ? v[c] : v[c + 8]);
@@ -285,6 +286,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
 // of work and two workgroups share a CU.
 #define RES_ROWS 288          // ceil(257 / 32) * 32: the PV / dK contraction steps read 32 rows at a time
 #define RES_NW 8
+#define RES_COLSUM_ROWS 8     // partial rows per sequence of the fused qkv bias gradient (dq: 8 waves; dk/dv: 4 waves + 4 zero rows)
 __global__ __launch_bounds__(RES_NW * 64, 4) void attn_fwd_res_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[2 * RES_ROWS * 128];          // K rows | V rows
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
@@ -633,6 +635,9 @@ __global__ __launch_bounds__(RES_NW * 64, 4) void attn_bwd_dq_res_kernel(AttnPar
 
     const int nqt = (T + 15) >> 4, nkt = (T + 63) / 64, nfull = T / 64;
     const int w0 = (wave + (bh >> 3)) & (RES_NW - 1);
+    f32x4 qsum[4];                                   // p.colsum: column sums of this wave's (rounded) dq rows
+#pragma unroll
+    for (int d = 0; d < 4; ++d) qsum[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int qt = w0; qt < nqt; qt += RES_NW) {
         const int q = qt * 16 + i;
         const int qc = q < T ? q : T - 1;
@@ -657,9 +662,12 @@ __global__ __launch_bounds__(RES_NW * 64, 4) void attn_bwd_dq_res_kernel(AttnPar
             for (int d = 0; d < 4; ++d) {
                 bf16x4 w = {f2bf(dq[d][0] * p.scale), f2bf(dq[d][1] * p.scale), f2bf(dq[d][2] * p.scale), f2bf(dq[d][3] * p.scale)};
                 *reinterpret_cast<bf16x4*>(dst + d * 16 + 4 * g) = w;
+                if (p.colsum) qsum[d] += f32x4{bf2f(w[0]), bf2f(w[1]), bf2f(w[2]), bf2f(w[3])};
             }
         }
     }
+    // qkv bias gradient: one partial row per (sequence, wave) -- RES_COLSUM_ROWS rows per sequence, this head's 64 columns
+    if (p.colsum) wave_colsum<false>(qsum, true, p.colsum + ((size_t)b * RES_COLSUM_ROWS + wave) * ld + h * HD, lane);
 }
 
 #define RES_DKDV_NW 4         // 4 waves x ~160 VGPRs (no spills), two workgroups per CU
@@ -691,6 +699,9 @@ __global__ __launch_bounds__(RES_DKDV_NW * 64, 2) void attn_bwd_dkdv_res_kernel(
 
     const int nkt16 = (T + 15) >> 4;
     const int w0 = (wave + (bh >> 3)) & (RES_DKDV_NW - 1);
+    f32x4 ksum[4], vsum[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) ksum[d] = vsum[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int kt = w0; kt < nkt16; kt += RES_DKDV_NW) {
         const int key = kt * 16 + i;
         const int kc = key < T ? key : T - 1;
@@ -716,7 +727,20 @@ __global__ __launch_bounds__(RES_DKDV_NW * 64, 2) void attn_bwd_dkdv_res_kernel(
                 bf16x4 wv = {f2bf(dv[d][0]), f2bf(dv[d][1]), f2bf(dv[d][2]), f2bf(dv[d][3])};
                 *reinterpret_cast<bf16x4*>(dst + D + d * 16 + 4 * g) = wk;
                 *reinterpret_cast<bf16x4*>(dst + 2 * D + d * 16 + 4 * g) = wv;
+                if (p.colsum) {
+                    ksum[d] += f32x4{bf2f(wk[0]), bf2f(wk[1]), bf2f(wk[2]), bf2f(wk[3])};
+                    vsum[d] += f32x4{bf2f(wv[0]), bf2f(wv[1]), bf2f(wv[2]), bf2f(wv[3])};
+                }
             }
+        }
+    }
+    if (p.colsum) {
+        float* row = p.colsum + ((size_t)b * RES_COLSUM_ROWS + wave) * ld + h * HD;
+        wave_colsum<false>(ksum, true, row + D, lane);
+        wave_colsum<false>(vsum, true, row + 2 * D, lane);
+        if (lane < 32) {                                 // rows 4..7 of the dk / dv columns: zeros (the dq kernel has 8 waves)
+            float* z = p.colsum + ((size_t)b * RES_COLSUM_ROWS + RES_DKDV_NW + wave) * ld + h * HD + (1 + (lane >> 4)) * D + (lane & 15) * 4;
+            *reinterpret_cast<f32x4*>(z) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
 }
@@ -744,7 +768,16 @@ extern "C" int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B,
 }
 
 // dqkv receives dq | dk | dv in the layout of qkv.  delta is [B,H,T] workspace.
-extern "C" int p4p_attention_colsum_rows(int B, int T) { return B * ceil_div(T, 64) * 4; }
+static bool attn_resident(int T) {
+    static const bool no_res = getenv("P4P_ATTN_NO_RES") != nullptr;          // A/B switch (tools/ab_bench.sh)
+    return T <= RES_ROWS - 31 && T >= 64 && !no_res;
+}
+static bool attn_resident_dkdv(int T) {
+    static const bool on = getenv("P4P_ATTN_NO_RES_DKDV") == nullptr;          // A/B switch; 4 waves x 220 VGPRs: -0.4 ms/step
+    return on && attn_resident(T);
+}
+// the partial-row layouts of the streaming and the resident kernels differ: dq and dk/dv take the same path when sums are asked for
+extern "C" int p4p_attention_colsum_rows(int B, int T) { return attn_resident_dkdv(T) ? B * RES_COLSUM_ROWS : B * ceil_div(T, 64) * 4; }
 
 // colsum_partial (may be null): [p4p_attention_colsum_rows(B,T)][3D] floats; their column sum (p4p_colreduce_f32) is
 // the column sum of dqkv = the gradient of the qkv bias.
@@ -760,9 +793,8 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
     AttnParams p = {};
     p.qkv = (const __bf16*)qkv; p.o = (const __bf16*)o; p.dout = (const __bf16*)dout; p.out = (__bf16*)dqkv;
     p.lse2 = (float*)lse2; p.delta = delta; p.colsum = colsum_partial; p.B = B; p.T = T; p.H = H; p.D = D; p.scale = scale;
-    static const bool no_res = getenv("P4P_ATTN_NO_RES") != nullptr;          // A/B switch (tools/ab_bench.sh)
-    static const bool res_dkdv = getenv("P4P_ATTN_NO_RES_DKDV") == nullptr;   // A/B switch; 4 waves x 220 VGPRs: -0.4 ms/step
-    const bool res = T <= RES_ROWS - 31 && T >= 64 && !colsum_partial && !no_res;
+    const bool res_dkdv = attn_resident_dkdv(T);
+    const bool res = attn_resident(T) && (res_dkdv || !colsum_partial);
     dim3 grid = attn_grid(B, T, H);
     if (res) hipLaunchKernelGGL(attn_bwd_dq_res_kernel, dim3(B * H), dim3(RES_NW * 64), 0, st, p);
     else hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(ATT_THREADS), 0, st, p);
