@@ -648,7 +648,18 @@ __global__ __launch_bounds__(RES_NW * 64, 4) void attn_bwd_dq_res_kernel(AttnPar
             dof[ks] = *reinterpret_cast<const bf16x8*>(p.dout + ((size_t)b * T + qc) * D + h * HD + ks * 32 + g * 8);
         }
         const size_t stat = ((size_t)b * p.H + h) * T + qc;
-        const float lse = p.lse2[stat], dl = p.delta[stat];
+        const float lse = p.lse2[stat];
+        // delta[q] = sum_d dO[q][d] * O[q][d], computed here from the dO fragments this wave holds anyway and published for
+        // the dK/dV kernel (which runs after this one): no separate attn_delta_kernel pass on the resident path
+        float dl = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 of = *reinterpret_cast<const bf16x8*>(p.o + ((size_t)b * T + qc) * D + h * HD + ks * 32 + g * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dl += bf2f(dof[ks][e]) * bf2f(of[e]);
+        }
+        dl = xor_lanes_sum(dl);
+        if (g == 0 && q < T) p.delta[stat] = dl;
         f32x4 dq[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -787,14 +798,16 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
     P4P_CHECK(qkv && o && dout && lse2 && delta && dqkv, "p4p_attention_bwd: null pointer");
     if (check_attn("p4p_attention_bwd", B, T, H, D)) return 1;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(ceil_div((long long)B * T, 4)), dim3(256), 0, st, (const __bf16*)o,
-                       (const __bf16*)dout, delta, B, T, H, D);
-    P4P_LAUNCH_CHECK();
+    const bool res_dkdv = attn_resident_dkdv(T);
+    const bool res = attn_resident(T) && (res_dkdv || !colsum_partial);
+    if (!res) {                                          // the resident dQ kernel computes delta itself
+        hipLaunchKernelGGL(attn_delta_kernel, dim3(ceil_div((long long)B * T, 4)), dim3(256), 0, st, (const __bf16*)o,
+                           (const __bf16*)dout, delta, B, T, H, D);
+        P4P_LAUNCH_CHECK();
+    }
     AttnParams p = {};
     p.qkv = (const __bf16*)qkv; p.o = (const __bf16*)o; p.dout = (const __bf16*)dout; p.out = (__bf16*)dqkv;
     p.lse2 = (float*)lse2; p.delta = delta; p.colsum = colsum_partial; p.B = B; p.T = T; p.H = H; p.D = D; p.scale = scale;
-    const bool res_dkdv = attn_resident_dkdv(T);
-    const bool res = attn_resident(T) && (res_dkdv || !colsum_partial);
     dim3 grid = attn_grid(B, T, H);
     if (res) hipLaunchKernelGGL(attn_bwd_dq_res_kernel, dim3(B * H), dim3(RES_NW * 64), 0, st, p);
     else hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(ATT_THREADS), 0, st, p);
