@@ -40,13 +40,15 @@ extern "C" int p4p_set_gemm_variant(int v) { int o = g_gemm_variant; g_gemm_vari
 // out[m][n] = sum_s part[s][m][n] + bias[n] (+ resid[m][n]), fixed order; fp32 or bf16 output
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int splits, long long plane,
                                                             const float* __restrict__ bias, const float* __restrict__ resid,
-                                                            void* __restrict__ out, int out_f32, int N) {
+                                                            const float* __restrict__ resid2, void* __restrict__ out, int out_f32,
+                                                            int N) {
     const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (e >= plane) return;
     f32x4 v = *reinterpret_cast<const f32x4*>(part + e);
     for (int s = 1; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(part + (size_t)s * plane + e);
     if (bias) v += *reinterpret_cast<const f32x4*>(bias + (int)(e % N));
     if (resid) v += *reinterpret_cast<const f32x4*>(resid + e);
+    if (resid2) v += *reinterpret_cast<const f32x4*>(resid2 + e);
     if (out_f32) {
         *reinterpret_cast<f32x4*>((float*)out + e) = v;
     } else {
@@ -139,6 +141,7 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
                 b.A = p.A + ro * p.K;
                 b.out = (char*)p.out + ro * p.N * (EPI == EPI_F32_RESID ? 4 : 2);
                 if (p.resid) b.resid = p.resid + ro * p.N;
+                if (EPI == EPI_F32_RESID && p.rowgrp) b.rowgrp = p.rowgrp + ro * p.N;          // second residual
                 if (p.pre) b.pre = p.pre + ro * p.N;
                 if (EPI == EPI_BF16_DGELU && p.stats) b.stats = p.stats + (size_t)2 * (a.M / 256) * p.N;   // rows behind the main part's
                 const int saved = g_gemm_variant;
@@ -168,11 +171,13 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
                         c.out = g_splitk_ws;
                         c.bias = nullptr;
                         c.resid = nullptr;
+                        c.rowgrp = nullptr;
                         int tiles = ceil_div(c.M, 64) * ceil_div(c.N, 64);
                         hipLaunchKernelGGL((gemm_tn2_kernel<64, 64, 2, 2, EPI_F32_RESID, false, 0>), dim3(tiles, splits), dim3(256), 0, st, c);
                         P4P_LAUNCH_CHECK();
                         hipLaunchKernelGGL(splitk_finish_kernel, dim3(ceil_div((long long)plane / 4, 256)), dim3(256), 0, st,
-                                           g_splitk_ws, splits, (long long)plane, b.bias, b.resid, b.out,
+                                           g_splitk_ws, splits, (long long)plane, b.bias, b.resid,
+                                           EPI == EPI_F32_RESID ? b.rowgrp : nullptr, b.out,
                                            EPI == EPI_F32_RESID ? 1 : 0, b.N);
                         P4P_LAUNCH_CHECK();
                     } else {
@@ -250,7 +255,8 @@ extern "C" int p4p_gemm_tn_bf16(int epi, const void* A, const void* W, void* out
         case EPI_BF16: return launch_tn<EPI_BF16>(p, st);
         case EPI_BF16_GELU: return launch_tn<EPI_BF16_GELU>(p, st);
         case EPI_F32_RESID:
-            P4P_CHECK(group <= 1 || !resid, "p4p_gemm_tn_bf16: EPI_F32_RESID with group > 1 (token-stream rows) takes no residual");
+            P4P_CHECK(group <= 1 || (!resid && !rowgrp), "p4p_gemm_tn_bf16: EPI_F32_RESID with group > 1 (token-stream rows) takes no residual");
+            P4P_CHECK(!rowgrp || resid, "p4p_gemm_tn_bf16: EPI_F32_RESID: a second residual (rowgrp slot) needs the first");
             return launch_tn<EPI_F32_RESID>(p, st);
         case EPI_BF16_DGELU:
             P4P_CHECK(pre, "p4p_gemm_tn_bf16: EPI_BF16_DGELU needs pre");

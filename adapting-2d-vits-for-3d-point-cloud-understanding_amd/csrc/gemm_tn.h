@@ -212,6 +212,7 @@ void gemm_tn2_kernel(GemmParams p) {
             if (EPI == EPI_F32_RESID) {
                 if (ok) {
                     if (p.resid) v += *reinterpret_cast<const f32x4*>(p.resid + o);
+                    if (p.rowgrp) v += *reinterpret_cast<const f32x4*>(p.rowgrp + o);           // second residual (gemm_tn3.h)
                     const size_t oo = p.group > 1 ? ((size_t)m + m / p.group + 1) * p.N + n : o;     // token-stream rows (gemm_tn3.h)
                     *reinterpret_cast<f32x4*>((float*)p.out + (size_t)blockIdx.y * p.M * p.N + oo) = v;
                 }

@@ -63,11 +63,17 @@ __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 
 
     if (EPI == EPI_F32_RESID) {
         const float* rsrc = p.resid ? p.resid + (size_t)colbase + g * 4 : nullptr;
+        // optional SECOND residual (passed in the rowgrp slot): x_next = x1 + fc2(.) + pos, so that the next block's
+        // LayerNorm reads one stream instead of x and pos and does not write their sum (src/models/pix4point.py:255)
+        const float* rsrc2 = p.rowgrp ? p.rowgrp + (size_t)colbase + g * 4 : nullptr;
         float* dst = (float*)p.out + (size_t)colbase + g * 4;
         auto row_of = [&](int j) { int m = rowbase + j * 16 + li; return m < p.M ? m : p.M - 1; };
         f32x4 rnext[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rnext[i] = rsrc ? *reinterpret_cast<const f32x4*>(rsrc + (size_t)row_of(0) * p.N + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; ++i) {
+            rnext[i] = rsrc ? *reinterpret_cast<const f32x4*>(rsrc + (size_t)row_of(0) * p.N + i * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rsrc2) rnext[i] += *reinterpret_cast<const f32x4*>(rsrc2 + (size_t)row_of(0) * p.N + i * 16);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             f32x4 rcur[4];
@@ -75,7 +81,10 @@ __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 
             for (int i = 0; i < 4; ++i) rcur[i] = rnext[i];
             if (j + 1 < 8 && rsrc) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rnext[i] = *reinterpret_cast<const f32x4*>(rsrc + (size_t)row_of(j + 1) * p.N + i * 16);
+                for (int i = 0; i < 4; ++i) {
+                    rnext[i] = *reinterpret_cast<const f32x4*>(rsrc + (size_t)row_of(j + 1) * p.N + i * 16);
+                    if (rsrc2) rnext[i] += *reinterpret_cast<const f32x4*>(rsrc2 + (size_t)row_of(j + 1) * p.N + i * 16);
+                }
             }
             const int m = rowbase + j * 16 + li;
             if (m < p.M) {

@@ -252,6 +252,8 @@ _BLOCK_PARAMS = 12     # n1w n1b qkvw qkvb projw projb n2w n2b fc1w fc1b fc2w fc
 # bias gradients of qkv / fc1 from inside the kernels that produce dqkv / dh (A/B switches for tools/, default on)
 _FUSE_QKV_BIAS = os.environ.get('P4P_FUSE_QKV_BIAS', '1') != '0'   # -0.75 ms/step with the resident attention kernels (T <= 257)
 _FUSE_FC1_BIAS = os.environ.get('P4P_FUSE_FC1_BIAS', '1') != '0'
+# blk(x + pos) (src/models/pix4point.py:255): the fc2 epilogue of block l adds pos for block l+1 (A/B switch)
+_POS_IN_FC2 = os.environ.get('P4P_POS_IN_FC2', '1') != '0'
 
 
 def block_params(blk):
@@ -274,8 +276,12 @@ class _EncoderFn(torch.autograd.Function):
         saved = []
         for l in range(L):
             n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = bp[l * _BLOCK_PARAMS:(l + 1) * _BLOCK_PARAMS]
-            ln1, xin, mean1, rstd1 = ops.layernorm_fwd(x, n1w.detach(), n1b.detach(), eps, pos=pos2, want_sum=True,
-                                                       want_stats=train)
+            if l == 0 or not _POS_IN_FC2:
+                ln1, xin, mean1, rstd1 = ops.layernorm_fwd(x, n1w.detach(), n1b.detach(), eps, pos=pos2, want_sum=True,
+                                                           want_stats=train)
+            else:       # x already is x_l + pos: the fc2 epilogue of the block below added it (one stream in, no sum written)
+                ln1, _, mean1, rstd1 = ops.layernorm_fwd(x, n1w.detach(), n1b.detach(), eps, want_stats=train)
+                xin = x
             Wqkv, _ = _bf16_weights(qkvw, train)
             qkv = ops.gemm_tn(ln1, Wqkv, ops.EPI_BF16, bias=qkvb.detach())
             att, lse = ops.attention_fwd(qkv, B, T, H, want_lse=train)
@@ -288,7 +294,8 @@ class _EncoderFn(torch.autograd.Function):
             else:
                 g, hpre = ops.gemm_tn(ln2, Wfc1, ops.EPI_BF16_GELU, bias=fc1b.detach()), None
             Wfc2, _ = _bf16_weights(fc2w, train)
-            x = ops.gemm_tn(g, Wfc2, ops.EPI_F32_RESID, bias=fc2b.detach(), resid=x1)
+            x = ops.gemm_tn(g, Wfc2, ops.EPI_F32_RESID, bias=fc2b.detach(), resid=x1,
+                            resid2=pos2 if (_POS_IN_FC2 and l + 1 < L) else None)
             if train:
                 saved += [xin, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, hpre, g]
         y, _, meanN, rstdN = ops.layernorm_fwd(x, norm_w.detach(), norm_b.detach(), eps, out_f32=True, want_stats=train)

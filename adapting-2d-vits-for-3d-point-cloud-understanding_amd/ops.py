@@ -70,7 +70,7 @@ def group_gather(src, idx):
 
 # ---------------------------------------------------------------- GEMMs
 def gemm_tn(a, w, epilogue=EPI_BF16, bias=None, resid=None, pre=None, rowgrp=None, group=1, out=None,
-            want_stats=False, want_pre=False, want_colsum=False):
+            want_stats=False, want_pre=False, want_colsum=False, resid2=None):
     """out[M,N] = a[M,K] @ w[N,K]^T with a fused epilogue (see include/p4p_hip.h).  want_colsum (EPI_BF16_DGELU
     only) also returns the column sums of out = the bias gradient of the Linear that produced `pre`."""
     _chk(a, 'a', torch.bfloat16, 2)
@@ -80,6 +80,11 @@ def gemm_tn(a, w, epilogue=EPI_BF16, bias=None, resid=None, pre=None, rowgrp=Non
     if w.shape[1] != K:
         raise RuntimeError(f'gemm_tn: a is {tuple(a.shape)}, w is {tuple(w.shape)}')
     f32_out = epilogue == EPI_F32_RESID
+    if resid2 is not None:                         # second fp32 residual: travels in the rowgrp slot of the C ABI
+        if not f32_out or resid is None or rowgrp is not None:
+            raise RuntimeError('gemm_tn: resid2 needs EPI_F32_RESID with resid')
+        _chk(resid2, 'resid2', torch.float32)
+        rowgrp = resid2
     if f32_out and group > 1:                      # token-stream rows: the caller provides the [B*(S+1), N] buffer
         if out is None or resid is not None or M % group or out.shape != (M // group * (group + 1), N):
             raise RuntimeError('gemm_tn: EPI_F32_RESID with group > 1 needs out [M/group*(group+1), N] and no resid')

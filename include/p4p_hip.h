@@ -42,7 +42,8 @@ int p4p_group_gather_f32(const float* src, const int32_t* idx, float* out, int B
 enum p4p_epilogue {
     P4P_EPI_BF16 = 0,          /* out bf16 = A W^T (+bias) */
     P4P_EPI_BF16_GELU = 1,     /* h = A W^T + bias; out bf16 = gelu(h); pre bf16 = gelu'(h) if pre (timm Mlp fc1+act) */
-    P4P_EPI_F32_RESID = 2,     /* out f32 = A W^T (+bias) (+resid f32)                      (proj / fc2 + residual);
+    P4P_EPI_F32_RESID = 2,     /* out f32 = A W^T (+bias) (+resid f32) (+ a second f32 residual passed as `rowgrp`: the next
+                                  block's x + pos_embed, pix4point.py:255)                 (proj / fc2 + residual);
                                   group = S > 1 (no resid): row m is written to row m + m/S + 1 of a [B*(S+1), N]
                                   token stream, i.e. behind one cls row per sequence (pix4point.py:248-252) */
     P4P_EPI_BF16_DGELU = 3,    /* out bf16 = (A W^T) * pre   (pre = the gelu'(h) saved by epilogue 1)  (backward of fc1's act) */
