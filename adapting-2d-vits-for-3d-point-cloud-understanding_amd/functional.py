@@ -349,14 +349,15 @@ class _EncoderFn(torch.autograd.Function):
             datt = ops.gemm_tn(dxb, WprojT, ops.EPI_BF16)
             if wg:
                 dprojw, dprojb = ops.gemm_wgrad(dxb, att), dx_colsum
-            if wg and _FUSE_QKV_BIAS:
+            fuse_qkvb = _FUSE_QKV_BIAS and T <= 257        # pays only with the resident kernels (streaming ones are VALU-bound)
+            if wg and fuse_qkvb:
                 dqkv, dqkvb = ops.attention_bwd(qkv, att, datt, lse, B, T, H, want_colsum=True)
             else:
                 dqkv = ops.attention_bwd(qkv, att, datt, lse, B, T, H)
             _, WqkvT = _bf16_weights(qkvw, True)
             dln1 = ops.gemm_tn(dqkv, WqkvT, ops.EPI_BF16)
             if wg:
-                if _FUSE_QKV_BIAS:
+                if fuse_qkvb:
                     dqkvw = ops.gemm_wgrad(dqkv, ln1)
                 else:
                     dqkvw, dqkvb = ops.gemm_wgrad(dqkv, ln1, want_bias=True)
