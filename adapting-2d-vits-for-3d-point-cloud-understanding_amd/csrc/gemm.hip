@@ -126,16 +126,16 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
         // 256 CUs = 3 rounds + 3 tiles -> a 4th round for 0.4% of the work, measured -15..20%), peel the last
         // row tile(s) off and run them with the 128x128 configuration (many small workgroups, one short round).
         const bool row_remap = EPI == EPI_F32_RESID && p.group > 1;      // token-stream output rows: no peeling / split-K
-        if ((v == 3 || v == 4 || v == 5 || v == 7 || v == 8 || v == 10) && p.M % 256 == 0 && !row_remap) {
+        if ((v == 3 || v == 4 || v == 5 || v == 7 || v == 8 || v == 10) && !row_remap) {
             const int bn = (v == 3 || v == 7 || v == 8 || v == 10) ? 256 : T3_BN, slots = (v == 3 || v == 7 || v == 8 || v == 10) ? 256 : 512;
-            const int tiles_n = ceil_div(p.N, bn), tiles_m = p.M / 256;
+            const int tiles_n = ceil_div(p.N, bn), tiles_m = ceil_div(p.M, 256);       // the last panel may be ragged: it is peeled first
             const long long total = (long long)tiles_m * tiles_n;
             const long long rounds = total / slots, rem = total % slots;
             static const int peel_max_rounds = getenv("P4P_PEEL_MAX_ROUNDS") ? atoi(getenv("P4P_PEEL_MAX_ROUNDS")) : 12;   // narrow N (<= 4 tiles per panel): measured at N=2048 (6 rounds + 3 tiles)
             if (rounds >= 1 && rounds <= (tiles_n <= 4 ? peel_max_rounds : 4) && rem > 0 && rem * 8 <= slots && rem % tiles_n == 0 && rem / tiles_n < tiles_m) {
-                const int peel = (int)(rem / tiles_n) * 256;            // rows handled by the small-tile launch
                 GemmParams a = p, b = p;
-                a.M = p.M - peel;
+                a.M = (tiles_m - (int)(rem / tiles_n)) * 256;           // whole panels for the big-tile launch
+                const int peel = p.M - a.M;                             // rows handled by the small-tile launch
                 const size_t ro = (size_t)a.M;
                 b.M = peel;
                 b.A = p.A + ro * p.K;
