@@ -353,7 +353,8 @@ def _attn_ref(qkv, B, T, H):
     return (a @ v).transpose(1, 2).reshape(B * T, D)
 
 
-@pytest.mark.parametrize('B,T,H', [(2, 1, 1), (2, 17, 3), (3, 64, 2), (2, 65, 3), (2, 257, 3), (1, 513, 2), (1, 2049, 1)])
+@pytest.mark.parametrize('B,T,H', [(2, 1, 1), (2, 17, 3), (3, 64, 2), (2, 65, 3), (2, 100, 2), (1, 129, 1), (2, 192, 2),
+                                   (2, 256, 2), (2, 257, 3), (2, 258, 1), (1, 513, 2), (1, 2049, 1)])
 def test_attention_fwd_bwd(B, T, H):
     D = 64 * H
     g = torch.Generator().manual_seed(T)
