@@ -1,0 +1,296 @@
+"""Autograd wiring of the HIP kernels for the AdaptPointFormer path.
+
+* ``apf_encoder`` - the point-group MLP of ``Encoder`` (reference src/models/apf.py:114-181): five 1x1 convolutions as
+  bf16 MFMA GEMMs over all B*G*gs points, train-mode BatchNorm statistics from the GEMM epilogues, the two max-pools
+  and the ``cat([global, local])`` folded into a per-group accumulator init (no 1536-channel concat is ever written).
+* ``apf_blocks``  - L x ``APFViTLayer`` (src/models/apf_utils.py:236-293) + ``encoder_norm`` (apf.py:364).  The block
+  weights are frozen in the reference (apf.py:335-346, adapters included), so the backward is the dgrad chain only.
+
+Everything here reuses the GEMM / attention / LayerNorm / BatchNorm kernels of the Pix4Point path; only
+``csrc/apf.hip`` is new.  torch is the allocator, the stream, the autograd graph and the (tiny) stochastic masks.
+"""
+import torch
+
+from . import ops
+from .functional import _bf16_weights
+
+
+# tests set this to a dict to receive the gating decisions of the next encoder forward (ReLU outputs F1/F2/F4 and the two
+# pool arg-max tensors), so that a PyTorch statement with IDENTICAL gates can check the backward kernels tightly
+_CAPTURE = None
+
+
+def _bn_after_bias(bn, scale, shift, bias, training):
+    """A conv bias in front of BatchNorm: cancels in train mode (it only moves running_mean), folds into the shift in
+    eval mode.  The GEMMs therefore run without it."""
+    if bias is None:
+        return shift
+    if training:
+        bn.running_mean.add_(bias.detach(), alpha=bn.momentum)
+        return shift
+    return shift + scale * bias.detach()
+
+
+def _split_hi_lo_weight(W1):
+    """[C,6] fp32 -> bf16 [C,64] = [W_hi, W_hi, W_lo, 0]: partner of the x0 layout of p4p_apf_group."""
+    C = W1.shape[0]
+    w = W1.detach().reshape(C, 6)
+    hi = w.bfloat16()
+    lo = (w - hi.float()).bfloat16()
+    out = torch.zeros(C, 64, dtype=torch.bfloat16, device=w.device)
+    out[:, 0:6], out[:, 6:12], out[:, 12:18] = hi, hi, lo
+    return out
+
+
+def split_hi_lo_input(pg):
+    """[P,6] fp32 -> bf16 [P,64] = [x_hi, x_lo, x_hi, 0] (what p4p_apf_group writes directly on the fused path)."""
+    hi = pg.bfloat16()
+    lo = (pg - hi.float()).bfloat16()
+    out = torch.zeros(pg.shape[0], 64, dtype=torch.bfloat16, device=pg.device)
+    out[:, 0:6], out[:, 6:12], out[:, 12:18] = hi, lo, hi
+    return out
+
+
+class _ApfEncoderFn(torch.autograd.Function):
+    """tokens f32 [B*G, E] from x0 bf16 [B*G*gs, 64]."""
+
+    @staticmethod
+    def forward(ctx, x0, G, gs, training, need_bwd, bns, W1, b1, g1, be1, W2, b2, g2, be2, W3, b3, W4, b4, g4, be4, W5, b5):
+        bn1, bn2, bn4 = bns
+        P = x0.shape[0]
+        C1, C2, E = W1.shape[0], W2.shape[0], W3.shape[0]
+
+        def bn(H, st, mod, bias):
+            C = H.shape[1]
+            sums = ops.colreduce(st, st.shape[0], 2 * C) if training else None
+            sc, sh, mean, istd = ops.bn_finalize(sums, mod, P, training)
+            sh = _bn_after_bias(mod, sc, sh, bias, training)
+            return ops.bn_relu(H, sc, sh), sc, sh, mean, istd
+
+        H1, st1 = ops.gemm_tn(x0, _split_hi_lo_weight(W1), ops.EPI_BF16_STATS)
+        F1, sc1, sh1, mean1, is1 = bn(H1, st1, bn1, b1)
+        W2b, W2T = _bf16_weights(W2, need_bwd)
+        H2, st2 = ops.gemm_tn(F1, W2b, ops.EPI_BF16_STATS)
+        F2, sc2, sh2, mean2, is2 = bn(H2, st2, bn2, b2)
+        W3b, W3T = _bf16_weights(W3, need_bwd)
+        f = ops.gemm_tn(F2, W3b, ops.EPI_BF16, bias=b3.detach())
+        fg, arg3 = ops.group_max(f, G, gs, out_f32=False)                       # apf.py:160
+        # second_conv[0] on cat([global.expand, local]) (apf.py:162-165): W4[:, :E] meets the pooled vector once per
+        # group and enters the per-point GEMM as its accumulator init
+        W4a, W4aT = _bf16_weights(W4, need_bwd, 0, E)
+        W4b, W4bT = _bf16_weights(W4, need_bwd, E, E)
+        U = ops.gemm_tn(fg, W4a, ops.EPI_F32_RESID)
+        H4, st4 = ops.gemm_tn(f, W4b, ops.EPI_BF16_ROWGROUP, rowgrp=U, group=gs)
+        F4, sc4, sh4, mean4, is4 = bn(H4, st4, bn4, b4)
+        W5b, W5T = _bf16_weights(W5, need_bwd)
+        H5 = ops.gemm_tn(F4, W5b, ops.EPI_BF16)
+        tok, arg5 = ops.group_max(H5, G, gs, bias=b5.detach())                  # apf.py:167
+        if training:
+            for m in bns:
+                m.num_batches_tracked += 1
+        if _CAPTURE is not None:
+            _CAPTURE.update(F1=F1, F2=F2, F4=F4, arg3=arg3, arg5=arg5)
+        ctx.training, ctx.dims = training, (G, gs, C1, C2, E)
+        ctx.save_for_backward(x0, H1, F1, sc1, sh1, mean1, is1, H2, F2, sc2, sh2, mean2, is2, f, fg, arg3, H4, F4, sc4,
+                              sh4, mean4, is4, arg5, W2T, W3T, W4aT, W4bT, W5T)
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        if not ctx.training:
+            raise RuntimeError('APF Encoder backward is implemented for train-mode BatchNorm only '
+                               '(the reference never back-propagates in eval mode)')
+        (x0, H1, F1, sc1, sh1, mean1, is1, H2, F2, sc2, sh2, mean2, is2, f, fg, arg3, H4, F4, sc4, sh4, mean4, is4, arg5,
+         W2T, W3T, W4aT, W4bT, W5T) = ctx.saved_tensors
+        G, gs, C1, C2, E = ctx.dims
+        dtok = dtok.contiguous().float()
+        db5 = dtok.sum(0)
+        dH5 = ops.group_max_bwd(dtok, arg5, G, gs)
+        dW5 = ops.gemm_wgrad(dH5, F4)
+        dF4 = ops.gemm_tn(dH5, W5T, ops.EPI_BF16)
+        del dH5
+        s4 = ops.relu_bn_bwd_(dF4, H4, sc4, sh4, mean4, is4)                    # dF4 now holds dH4
+        dW4b = ops.gemm_wgrad(dF4, f)
+        df = ops.gemm_tn(dF4, W4bT, ops.EPI_BF16)
+        dU = ops.group_sum(dF4, G, gs)
+        del dF4
+        dW4a = ops.gemm_wgrad(dU, fg)
+        dfg = ops.gemm_tn(dU, W4aT, ops.EPI_BF16)
+        ops.group_max_bwd(dfg, arg3, G, gs, into=df)                            # the pooled vector's share joins df
+        dW3, db3 = ops.gemm_wgrad(df, F2, want_bias=True)
+        dF2 = ops.gemm_tn(df, W3T, ops.EPI_BF16)
+        del df
+        s2 = ops.relu_bn_bwd_(dF2, H2, sc2, sh2, mean2, is2)
+        dW2 = ops.gemm_wgrad(dF2, F1)
+        dF1 = ops.gemm_tn(dF2, W2T, ops.EPI_BF16)
+        del dF2
+        s1 = ops.relu_bn_bwd_(dF1, H1, sc1, sh1, mean1, is1)
+        dW1p = ops.gemm_wgrad(dF1, x0)                                          # [C1, 64]: hi and lo input columns
+        dW1 = dW1p[:, 0:6] + dW1p[:, 6:12]
+        zeros = lambda n: torch.zeros(n, dtype=torch.float32, device=dtok.device)   # a bias in front of train-mode BN
+        dW4 = torch.cat([dW4a, dW4b], dim=1)
+        return (None, None, None, None, None, None,
+                dW1.reshape(C1, 6, 1), zeros(C1), s1[1].clone(), s1[0].clone(),
+                dW2.unsqueeze(-1), zeros(C2), s2[1].clone(), s2[0].clone(),
+                dW3.unsqueeze(-1), db3,
+                dW4.unsqueeze(-1), zeros(2 * E), s4[1].clone(), s4[0].clone(),
+                dW5.unsqueeze(-1), db5)
+
+
+def apf_encoder(x0, G, gs, training, enc):
+    """enc = Encoder module (first_conv / second_conv Sequentials, apf.py:129-143); x0 from ops.apf_group."""
+    fc, sc = enc.first_conv, enc.second_conv
+    bns = (fc[1], fc[4], sc[1])
+    need_bwd = bool(training and torch.is_grad_enabled() and any(p.requires_grad for p in enc.parameters()))
+    return _ApfEncoderFn.apply(x0, G, gs, training, need_bwd, bns, fc[0].weight, fc[0].bias, fc[1].weight, fc[1].bias,
+                               fc[3].weight, fc[3].bias, fc[4].weight, fc[4].bias, fc[6].weight, fc[6].bias,
+                               sc[0].weight, sc[0].bias, sc[1].weight, sc[1].bias, sc[3].weight, sc[3].bias)
+
+
+# ================================================================================================
+# L x APFViTLayer (+ encoder_norm)
+# ================================================================================================
+_APF_BLOCK_PARAMS = 19   # n1w n1b qkvw qkvb projw projb n2w n2b fc1w fc1b fc2w fc2b | anw anb scale dw db uw ub
+
+
+def apf_block_params(blk):
+    a = blk.adapter
+    return [blk.norm1.weight, blk.norm1.bias, blk.attention.qkv.weight, blk.attention.qkv.bias, blk.attention.proj.weight,
+            blk.attention.proj.bias, blk.norm2.weight, blk.norm2.bias, blk.mlp.fc1.weight, blk.mlp.fc1.bias,
+            blk.mlp.fc2.weight, blk.mlp.fc2.bias, a.adapter_norm.weight, a.adapter_norm.bias, a.scale, a.down_proj.weight,
+            a.down_proj.bias, a.up_proj.weight, a.up_proj.bias]
+
+
+class _ApfBlocksFn(torch.autograd.Function):
+    """x f32 [B,T,D] -> L blocks -> optional final LayerNorm.  Per block (apf_utils.py:277-293):
+        x1  = x + s_a * attention(norm1(x))
+        r   = up(drop(relu(down(adapter_norm(x1))))) * scale + 2 * x1       (adapter output + the block's own residual)
+        out = s_m * mlp(norm2(x1)) + r
+    s_a / s_m are the per-sample DropPath factors (None = identity).  The up-projection GEMM writes r directly (two
+    residual inputs), the fc2 GEMM adds r in its epilogue: no elementwise pass exists on the deterministic path."""
+
+    @staticmethod
+    def forward(ctx, x, num_heads, eps, train, drop_masks, adapter_p, norm_w, norm_b, *bp):
+        B, T, D = x.shape
+        M, H = B * T, num_heads
+        L = len(bp) // _APF_BLOCK_PARAMS
+        x = x.reshape(M, D).contiguous()
+        saved, scal = [], []
+        for l in range(L):
+            (n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, anw, anb, ascale, dw, db, uw,
+             ub) = bp[l * _APF_BLOCK_PARAMS:(l + 1) * _APF_BLOCK_PARAMS]
+            s_a, s_m = drop_masks[l] if drop_masks is not None else (None, None)
+            xin = x
+            ln1, _, mean1, rstd1 = ops.layernorm_fwd(xin, n1w.detach(), n1b.detach(), eps, want_stats=train)
+            Wqkv, _ = _bf16_weights(qkvw, train)
+            qkv = ops.gemm_tn(ln1, Wqkv, ops.EPI_BF16, bias=qkvb.detach())
+            att, lse = ops.attention_fwd(qkv, B, T, H, want_lse=train)
+            Wproj, _ = _bf16_weights(projw, train)
+            if s_a is None:
+                x1 = ops.gemm_tn(att, Wproj, ops.EPI_F32_RESID, bias=projb.detach(), resid=xin)
+            else:
+                y = ops.gemm_tn(att, Wproj, ops.EPI_F32_RESID, bias=projb.detach())
+                x1 = torch.addcmul(xin.view(B, T, D), y.view(B, T, D), s_a.view(B, 1, 1)).view(M, D)
+            # ---- adapter (apf_utils.py:217-233)
+            aln, _, meanA, rstdA = ops.layernorm_fwd(x1, anw.detach(), anb.detach(), eps, want_stats=train)
+            Wd, _ = _bf16_weights(dw, train)
+            pre = ops.gemm_tn(aln, Wd, ops.EPI_F32_RESID, bias=db.detach())        # [M, 64] f32
+            dmask = (pre > 0).to(torch.float32)
+            if adapter_p > 0:
+                dmask = dmask * (torch.rand_like(pre) >= adapter_p).to(torch.float32) / (1.0 - adapter_p)
+            down = (pre * dmask).bfloat16()
+            sc = ascale.detach().reshape(())
+            Wu = (uw.detach() * sc).bfloat16()                                     # [D, 64], scale folded in
+            r = ops.gemm_tn(down, Wu, ops.EPI_F32_RESID, bias=ub.detach() * sc, resid=x1, resid2=x1)
+            # ---- mlp
+            ln2, _, mean2, rstd2 = ops.layernorm_fwd(x1, n2w.detach(), n2b.detach(), eps, want_stats=train)
+            Wfc1, _ = _bf16_weights(fc1w, train)
+            if train:
+                g, hpre = ops.gemm_tn(ln2, Wfc1, ops.EPI_BF16_GELU, bias=fc1b.detach(), want_pre=True)
+            else:
+                g, hpre = ops.gemm_tn(ln2, Wfc1, ops.EPI_BF16_GELU, bias=fc1b.detach()), None
+            Wfc2, _ = _bf16_weights(fc2w, train)
+            if s_m is None:
+                x = ops.gemm_tn(g, Wfc2, ops.EPI_F32_RESID, bias=fc2b.detach(), resid=r)
+            else:
+                y = ops.gemm_tn(g, Wfc2, ops.EPI_F32_RESID, bias=fc2b.detach())
+                x = torch.addcmul(r.view(B, T, D), y.view(B, T, D), s_m.view(B, 1, 1)).view(M, D)
+            if train:
+                saved += [xin, mean1, rstd1, qkv, att, lse, x1, meanA, rstdA, dmask, Wu.t().contiguous(), mean2, rstd2, hpre]
+                scal.append((s_a, s_m))
+        if norm_w is not None:
+            y, _, meanN, rstdN = ops.layernorm_fwd(x, norm_w.detach(), norm_b.detach(), eps, out_f32=True, want_stats=train)
+        else:
+            y, meanN, rstdN = x, None, None
+        if train:
+            nw = norm_w if norm_w is not None else x.new_empty(0)
+            ctx.save_for_backward(x, meanN if meanN is not None else x.new_empty(0),
+                                  rstdN if rstdN is not None else x.new_empty(0), nw, *bp, *saved)
+        ctx.meta = (B, T, D, H, L, eps, norm_w is not None)
+        ctx.scal = scal
+        return y.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, T, D, H, L, eps, has_norm = ctx.meta
+        M = B * T
+        t = ctx.saved_tensors
+        xN, meanN, rstdN, norm_w = t[:4]
+        bp = t[4:4 + L * _APF_BLOCK_PARAMS]
+        saved = t[4 + L * _APF_BLOCK_PARAMS:]
+        if any(ctx.needs_input_grad[8:]):
+            raise NotImplementedError('APFViTLayer weights are frozen in the reference (apf.py:335-346, adapters included); '
+                                      'their weight gradients are not built')
+        dev = dy.device
+        dxb = torch.empty(M, D, dtype=torch.bfloat16, device=dev)
+        dnw = dnb = None
+        if has_norm:
+            dx, dnw, dnb = ops.layernorm_bwd(dy.reshape(M, D).contiguous(), xN, meanN, rstdN, norm_w.detach(), dx_bf16=dxb)
+        else:
+            dx = dy.reshape(M, D).contiguous().float().clone()
+            dxb.copy_(dx)
+
+        def scaled(s):                                                            # bf16 rows of dx times the DropPath factor
+            return dxb if s is None else (dx.view(B, T, D) * s.view(B, 1, 1)).to(torch.bfloat16).view(M, D)
+
+        NS = 14
+        for l in reversed(range(L)):
+            (n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, anw, anb, ascale, dw, db, uw,
+             ub) = bp[l * _APF_BLOCK_PARAMS:(l + 1) * _APF_BLOCK_PARAMS]
+            xin, mean1, rstd1, qkv, att, lse, x1, meanA, rstdA, dmask, WuT, mean2, rstd2, hpre = saved[l * NS:(l + 1) * NS]
+            s_a, s_m = ctx.scal[l]
+            # ---- mlp branch
+            _, Wfc2T = _bf16_weights(fc2w, True)
+            dh = ops.gemm_tn(scaled(s_m), Wfc2T, ops.EPI_BF16_DGELU, pre=hpre)
+            _, Wfc1T = _bf16_weights(fc1w, True)
+            dln2 = ops.gemm_tn(dh, Wfc1T, ops.EPI_BF16)
+            del dh
+            # ---- adapter branch: r = up(down) + 2 x1
+            ddown = ops.gemm_tn(dxb, WuT, ops.EPI_F32_RESID)                       # [M, 64] f32
+            dpre = (ddown * dmask).bfloat16()
+            _, WdT = _bf16_weights(dw, True)
+            daln = ops.gemm_tn(dpre, WdT, ops.EPI_BF16)
+            dx.mul_(2.0)
+            ops.layernorm_bwd(dln2, x1, mean2, rstd2, n2w.detach(), dx=dx)
+            ops.layernorm_bwd(daln, x1, meanA, rstdA, anw.detach(), dx=dx, dx_bf16=dxb)
+            # ---- attention branch
+            _, WprojT = _bf16_weights(projw, True)
+            datt = ops.gemm_tn(scaled(s_a), WprojT, ops.EPI_BF16)
+            dqkv = ops.attention_bwd(qkv, att, datt, lse, B, T, H)
+            _, WqkvT = _bf16_weights(qkvw, True)
+            dln1 = ops.gemm_tn(dqkv, WqkvT, ops.EPI_BF16)
+            del dqkv, datt
+            ops.layernorm_bwd(dln1, xin, mean1, rstd1, n1w.detach(), dx=dx, dx_bf16=dxb)
+        return (dx.view(B, T, D), None, None, None, None, None, dnw, dnb, *([None] * (L * _APF_BLOCK_PARAMS)))
+
+
+def apf_blocks(x, blocks, norm, num_heads, drop_masks=None, adapter_p=0.0):
+    """blocks: iterable of APFViTLayer; norm: LayerNorm or None; drop_masks: per block (s_attn, s_mlp) of shape (B,) or None."""
+    bp = []
+    for blk in blocks:
+        bp += apf_block_params(blk)
+    eps = blocks[0].norm1.eps
+    nw, nb = (norm.weight, norm.bias) if norm is not None else (None, None)
+    train = bool(torch.is_grad_enabled() and (x.requires_grad or (nw is not None and nw.requires_grad)
+                                              or any(p.requires_grad for p in bp)))
+    return _ApfBlocksFn.apply(x, num_heads, eps, train, drop_masks, float(adapter_p), nw, nb, *bp)

@@ -422,3 +422,65 @@ def embed_stage1_bwd(points, feats, idx, F1, dF1, dPooled, arg, mom, aeff, W1, W
            L.ptr(arg), L.ptr(part), L.ptr(sums), L.ptr(mom), L.ptr(aeff), L.ptr(W1), L.ptr(W2), L.ptr(gamma),
            L.ptr(invstd), L.ptr(dW1), L.ptr(dW2), L.ptr(db2), L.ptr(dg), L.ptr(db), 0.0, B, N, S, k, C1, _stream())
     return dW1, dW2, db2, dg, db
+
+
+# ---------------------------------------------------------------- AdaptPointFormer tokenizer glue
+def morton_order(centers, resolution=1024, want_codes=False):
+    """MortonEncoder.points_to_morton (reference src/models/apf_utils.py:67-104) -> int32 (B,G) permutation."""
+    _chk(centers, 'centers', torch.float32, 3)
+    B, G, D = centers.shape
+    if D != 3:
+        raise RuntimeError(f'centers: last dim must be 3 (xyz), got {D}')
+    order = torch.empty(B, G, dtype=torch.int32, device=centers.device)
+    codes = torch.empty(B, G, dtype=torch.int32, device=centers.device) if want_codes else None
+    L.call('p4p_morton_order_f32', L.ptr(centers), L.ptr(order), L.ptr(codes), B, G, int(resolution), _stream())
+    return (order, codes) if want_codes else order
+
+
+def apf_group(x, fps_idx, knn_idx, order, want_f32=False, want_x0=True, want_center=True):
+    """Group.forward after the index ops (reference src/models/apf.py:70-110).  Returns (nb_f32 | None, x0_bf16 | None,
+    center | None), rows in Morton order."""
+    _chk(x, 'x', torch.float32, 3)
+    _chk(fps_idx, 'fps_idx', torch.int64, 2)
+    _chk(knn_idx, 'knn_idx', torch.int32, 3)
+    _chk(order, 'order', torch.int32, 2)
+    B, N, C = x.shape
+    if C != 3:
+        raise RuntimeError(f'apf_group: built for in_channels=3 (xyz only), got {C} channels')
+    G, gs = knn_idx.shape[1], knn_idx.shape[2]
+    if fps_idx.shape != (B, G) or order.shape != (B, G) or knn_idx.shape[0] != B:
+        raise RuntimeError('apf_group: index shapes do not match')
+    dev = x.device
+    nb = torch.empty(B, G, gs, 6, dtype=torch.float32, device=dev) if want_f32 else None
+    x0 = torch.empty(B * G * gs, 64, dtype=torch.bfloat16, device=dev) if want_x0 else None
+    cen = torch.empty(B, G, 3, dtype=torch.float32, device=dev) if want_center else None
+    L.call('p4p_apf_group', L.ptr(x), L.ptr(fps_idx), L.ptr(knn_idx), L.ptr(order), L.ptr(nb), L.ptr(x0), L.ptr(cen), B, N, G,
+           gs, _stream())
+    return nb, x0, cen
+
+
+def group_max(H, G, k, bias=None, out_f32=True, want_arg=True):
+    """max over the k rows of every group of H [G*k, C] bf16 (+ bias) -> (tok [G,C] f32 or bf16, arg u8 | None)."""
+    _chk(H, 'H', torch.bfloat16, 2)
+    C = H.shape[1]
+    if H.shape[0] != G * k:
+        raise RuntimeError('group_max: H must be (G*k, C)')
+    tok = torch.empty(G, C, dtype=torch.float32 if out_f32 else torch.bfloat16, device=H.device)
+    arg = torch.empty(G, C, dtype=torch.uint8, device=H.device) if want_arg else None
+    L.call('p4p_group_max_bf16', L.ptr(H), L.ptr(bias), L.ptr(tok) if out_f32 else None, None if out_f32 else L.ptr(tok),
+           L.ptr(arg), L.i64(G), int(k), C, _stream())
+    return tok, arg
+
+
+def group_max_bwd(dtok, arg, G, k, into=None):
+    """dH [G*k, C] bf16 = dtok scattered to the arg-max rows; `into` accumulates in place instead."""
+    _chk(dtok, 'dtok', None, 2)
+    if dtok.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError('group_max_bwd: dtok must be f32 or bf16')
+    _chk(arg, 'arg', torch.uint8, 2)
+    C = dtok.shape[1]
+    dH = into if into is not None else torch.empty(G * k, C, dtype=torch.bfloat16, device=dtok.device)
+    _chk(dH, 'dH', torch.bfloat16, 2)
+    L.call('p4p_group_max_bwd', L.ptr(dtok), int(dtok.dtype == torch.float32), L.ptr(arg), L.ptr(dH), int(into is not None),
+           L.i64(G), int(k), C, _stream())
+    return dH

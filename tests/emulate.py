@@ -38,3 +38,34 @@ def p3embed_emulated(points, idx, params, k, eps=1e-5):
     h3 = f2 @ _r(params['1.3.weight'].reshape(256, 512)).t()
     _, _, sc3, sh3 = _bn_train(h3, params['1.4.weight'], params['1.4.bias'], eps)
     return torch.relu(_r(h3) * sc3 + sh3).view(B * S, k, 256).max(1).values
+
+
+def apf_encoder_emulated(x6, params, G, gs, eps=1e-5, gates=None):
+    """x6 [G*gs, 6] f32; params = dict of fp32 leaf tensors named like Encoder's state dict (first_conv.N.* /
+    second_conv.N.*).  Tokens [G, E] computed the way functional_apf._ApfEncoderFn does: bf16 storage of H1, F1, H2, F2,
+    f, H4, F4, H5 and of the GEMM weight operands; BatchNorm statistics from the fp32 accumulators; conv biases in front
+    of a train-mode BatchNorm dropped (they cancel).  ``gates`` (functional_apf._CAPTURE of the kernel run) replaces every
+    ReLU / arg-max decision by the kernels' own, so that the two backward passes differ by arithmetic only: with bf16
+    storage in front of a 32-way max, one-ulp differences would otherwise move ~0.3 % of the arg-max picks."""
+    p = params
+    E = p['first_conv.6.weight'].shape[0]
+    w = lambda n: p[n].reshape(p[n].shape[0], -1)
+
+    def bn_relu(h, pre, key):
+        _, _, sc, sh = _bn_train(h, p[pre + '.weight'], p[pre + '.bias'], eps)
+        z = _r(h) * sc + sh
+        return _r(torch.relu(z) if gates is None else z * (gates[key] > 0).float())
+
+    def pool(h, key):
+        h = h.view(G, gs, E)
+        return h.max(1).values if gates is None else h.gather(1, gates[key].long().unsqueeze(1)).squeeze(1)
+
+    f1 = bn_relu(x6 @ w('first_conv.0.weight').t(), 'first_conv.1', 'F1')      # hi/lo split: fp32-class product
+    f2 = bn_relu(f1 @ _r(w('first_conv.3.weight')).t(), 'first_conv.4', 'F2')
+    f = _r(f2 @ _r(w('first_conv.6.weight')).t() + p['first_conv.6.bias'])
+    fg = pool(f, 'arg3')
+    W4 = w('second_conv.0.weight')
+    u = fg @ _r(W4[:, :E]).t()
+    f4 = bn_relu(f @ _r(W4[:, E:]).t() + u.repeat_interleave(gs, 0), 'second_conv.1', 'F4')
+    h5 = _r(f4 @ _r(w('second_conv.3.weight')).t())
+    return pool(h5, 'arg5') + p['second_conv.3.bias']
