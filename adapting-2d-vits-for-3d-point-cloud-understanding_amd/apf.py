@@ -106,14 +106,14 @@ class _DropPath(nn.Module):
 
 
 def drop_factors(blk, B, device, training):
-    """(s_attn, s_mlp): per-sample Bernoulli(keep)/keep factors of the block's two DropPath calls (independent draws,
-    apf_utils.py:280,290), or (None, None) when DropPath is the identity."""
+    """(keep_attn, keep_mlp, 1/keep_prob): the per-sample Bernoulli(keep) draws of the block's two DropPath calls
+    (independent, apf_utils.py:280,290) as bool (B,) tensors, or (None, None, 1.0) when DropPath is the identity."""
     p = getattr(blk.drop_path, 'drop_prob', 0.0)
     if not training or p <= 0.0:
-        return None, None
+        return None, None, 1.0
     keep = 1.0 - p
-    draw = lambda: (torch.rand(B, device=device) < keep).to(torch.float32) / keep
-    return draw(), draw()
+    draw = lambda: torch.rand(B, device=device) < keep
+    return draw(), draw(), 1.0 / keep
 
 
 class APFViTLayer(nn.Module):

@@ -1,0 +1,144 @@
+"""Drop-in for the reference's ``src/train/apf_trainer.py`` (same constructor, dict-config keys, ``train()``, CSV schema
+with the ``learning_rate`` column, checkpoint dict and file names), running the HIP AdaptPointFormer; one process per GPU
+with an RCCL all-reduce of the (few) trainable gradients when launched under torch.distributed.
+
+The training step is the reference's (:260-275): zero_grad, forward, CrossEntropy(label_smoothing), backward, AdamW over
+``model.parameters()`` - no gradient clipping on this path.  ``CosineWarmupLR`` restates the per-epoch schedule the
+reference takes from ``timm.scheduler.CosineLRScheduler`` (:177-183; timm is absent, so this piece is unpinned): linear
+warm-up from ``warmup_lr_init`` over ``warmup_t`` epochs, then one cosine cycle to 0 over ``t_initial`` epochs.
+"""
+import csv
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from .apf import AdaptPointFormer
+from .ddp import GradReducer, broadcast_parameters
+from .optim import FusedAdamW
+from .trainer import Pix4PointTrainer, SyntheticClouds
+
+
+class CosineWarmupLR:
+    def __init__(self, optimizer, t_initial, warmup_t=0, warmup_lr_init=0.0, lr_min=0.0):
+        self.optimizer, self.t_initial, self.warmup_t = optimizer, t_initial, warmup_t
+        self.warmup_lr_init, self.lr_min = warmup_lr_init, lr_min
+        self.base = [g['lr'] for g in optimizer.param_groups]
+        self.step(0) if warmup_t > 0 else None           # timm starts at the warm-up value
+
+    def lr_at(self, t, base):
+        if t < self.warmup_t:
+            return self.warmup_lr_init + t * (base - self.warmup_lr_init) / self.warmup_t
+        if t >= self.t_initial:                          # past the single cycle
+            return self.lr_min
+        return self.lr_min + 0.5 * (base - self.lr_min) * (1 + math.cos(math.pi * t / self.t_initial))
+
+    def step(self, epoch):
+        for g, b in zip(self.optimizer.param_groups, self.base):
+            g['lr'] = self.lr_at(epoch, b)
+
+
+class APFTrainer(Pix4PointTrainer):
+    """Trainer for AdaptPointFormer (reference apf_trainer.py:20-345); the epoch loops are the shared ones."""
+
+    def __init__(self, model_config: dict, dataset_config: dict, train_config: dict, device: str = "cpu",
+                 output_dir: str = "./output") -> None:
+        super().__init__(model_config, dataset_config, train_config, device, output_dir)
+
+    # ---- reference :64-82
+    def _init_model(self) -> None:
+        c = self.model_config
+        self.model = AdaptPointFormer(num_classes=c['num_classes'], in_channels=c['in_channels'], vit_name=c['vit_name'],
+                                      pretrained=c.get('pretrained', True), embedding_dim=c.get('embedding_dim', 768),
+                                      npoint=c.get('npoint', 196), nsample=c.get('nsample', 32),
+                                      dropout_rate=c.get('dropout_rate', 0.1),
+                                      dropout_path_rate=c.get('drop_path_rate', 0.1),
+                                      depth=c.get('depth', 12), num_heads=c.get('num_heads', 12))   # additive keys
+        self.model.to(self.device)
+        broadcast_parameters(self.model)
+        self.reducer = (GradReducer([[p for p in self.model.parameters() if p.requires_grad]])
+                        if self.distributed else None)
+
+    # ---- reference :84-146 (ScanObjectNN reader: later-round item, as in trainer.py)
+    def _init_datasets(self) -> None:
+        c = self.dataset_config
+        if c.get('root_dir') != 'synthetic':
+            raise NotImplementedError("ScanObjectNN loading is a later-round item (SURVEY.md section 8f-3); "
+                                      "use dataset_config['root_dir']='synthetic'")
+        n = c.get('num_samples', 2048)
+        k = self.model_config['num_classes']
+        self.train_dataset = SyntheticClouds(n, c['train_num_points'], k, seed=1234)
+        self.test_dataset = SyntheticClouds(max(n // 4, 1), c['test_num_points'], k, seed=4321)
+
+    # ---- reference :164-183
+    def _init_optimizer(self) -> None:
+        t = self.train_config
+        self.criterion = nn.CrossEntropyLoss(label_smoothing=t.get('label_smoothing', 0.3))
+        self.optimizer = FusedAdamW(self.model.parameters(), betas=(0.9, 0.999), eps=1e-8, lr=t['learning_rate'],
+                                    weight_decay=t['weight_decay'])
+        self.scheduler = CosineWarmupLR(self.optimizer, t_initial=t['epochs'], warmup_t=t.get('warmup_epochs', 10),
+                                        warmup_lr_init=t.get('warmup_lr_init', 1e-3))
+
+    # ---- reference :185-203
+    def _init_metrics_csv(self) -> None:
+        with open(self.metrics_csv_path, 'w', newline='') as f:
+            csv.writer(f).writerow(['epoch', 'train_loss', 'train_accuracy', 'test_loss', 'test_accuracy', 'learning_rate'])
+
+    def _update_metrics_csv(self, epoch, train_loss, train_acc, test_loss, test_acc) -> None:
+        with open(self.metrics_csv_path, 'a', newline='') as f:
+            csv.writer(f).writerow([epoch + 1, train_loss, train_acc, test_loss, test_acc,
+                                    self.optimizer.param_groups[0]['lr']])
+
+    # ---- one optimisation step (reference :260-275); also what bench.py --workload apf times
+    def train_step(self, points: torch.Tensor, labels: torch.Tensor, start_idx=None):
+        if self.reducer is not None:
+            self.reducer.zero_grad()
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+        logits = self.model(points, start_idx)
+        loss = self.criterion(logits, labels)
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.optimizer.step()
+        return loss, logits
+
+    # ---- reference :205-247: the scheduler is stepped with the epoch index after the test phase
+    def train(self) -> None:
+        best_acc = 0.0
+        for epoch in range(self.train_config['epochs']):
+            if self.rank == 0:
+                print(f"\nEpoch {epoch+1}/{self.train_config['epochs']}")
+                print(f"Current learning rate: {self.optimizer.param_groups[0]['lr']:.6f}")
+            if self.distributed:
+                self.train_loader.sampler.set_epoch(epoch)
+            train_loss, train_acc = self._train_epoch()
+            test_loss, test_acc = self._test_epoch()
+            if self.rank == 0:
+                self._update_metrics_csv(epoch, train_loss, train_acc, test_loss, test_acc)
+                if test_acc > best_acc:
+                    best_acc = test_acc
+                    self._save_checkpoint("model_best.pt", epoch, test_acc)
+                    print(f"New best model saved with accuracy: {best_acc:.4f}")
+                if (epoch + 1) % self.train_config['save_interval'] == 0:
+                    self._save_checkpoint(f"model_epoch_{epoch+1}.pt", epoch, test_acc)
+                print(f"Epoch {epoch+1} results:")
+                print(f"  Train Loss: {train_loss:.4f}, Train Accuracy: {train_acc:.4f}")
+                print(f"  Test Loss: {test_loss:.4f}, Test Accuracy: {test_acc:.4f}")
+            self.scheduler.step(epoch)
+        if self.rank == 0:
+            print(f"\nTraining completed. Best test accuracy: {best_acc:.4f}")
+            print(f"Training metrics saved to {self.metrics_csv_path}")
+
+    def _train_epoch(self):
+        sched, self.scheduler = self.scheduler, _NoStep()          # the shared loop steps a per-epoch scheduler itself
+        try:
+            return super()._train_epoch()
+        finally:
+            self.scheduler = sched
+
+
+class _NoStep:
+    def step(self, *a):
+        pass

@@ -4,6 +4,8 @@
 //   p4p_apf_group        : gather + centre-relative concat + Morton reorder of the kNN groups   (apf.py:70-110)
 //   p4p_group_max_bf16   : max over the points of a group (+ channel bias), with arg-max         (apf.py:160,167)
 //   p4p_group_max_bwd    : the matching scatter of the token gradient
+//   p4p_rows_restore_f32 / p4p_rows_zero_bf16 : DropPath (apf_utils.py:280,290) as a row fix-up that touches only the
+//                          dropped samples; the 1/keep factor lives in the (frozen) weights
 // All HBM-bound byte/integer work: one coalesced pass each, nothing reshaped into a GEMM.
 #include "common.h"
 
@@ -248,6 +250,106 @@ extern "C" int p4p_group_max_bwd(const void* dtok, int dtok_is_f32, const uint8_
     P4P_CHECK(G >= 1 && k >= 1 && k <= 255 && C >= 4 && C % 4 == 0, "p4p_group_max_bwd: bad sizes G=%lld k=%d C=%d", G, k, C);
     hipLaunchKernelGGL(group_max_bwd_kernel, dim3(ceil_div(G * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, dtok,
                        dtok_is_f32, arg, (__bf16*)dH, accumulate, G, k, C);
+    P4P_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// DropPath without an elementwise pass.  x1 = x + (mask/keep) * branch(x): the GEMM that ends the branch runs with weights
+// and bias pre-scaled by 1/keep and adds the residual for EVERY sample; afterwards the rows of the dropped samples
+// (keep[b] == 0, ~p of them) are put back to the residual.  In the backward the branch gradient of those samples is zeroed
+// the same way.  Workgroups of kept samples return after one byte load.
+// ---------------------------------------------------------------------------------------------
+#define ROWFIX_SLABS 32
+__global__ void rows_restore_kernel(float* __restrict__ dst, const float* __restrict__ src, const uint8_t* __restrict__ keep,
+                                    long long per_sample) {
+    const int b = blockIdx.y;
+    if (keep[b]) return;
+    const long long slab = (per_sample / 4 + ROWFIX_SLABS - 1) / ROWFIX_SLABS;
+    const long long lo = (long long)blockIdx.x * slab, hi = lo + slab < per_sample / 4 ? lo + slab : per_sample / 4;
+    f32x4* d = reinterpret_cast<f32x4*>(dst + (size_t)b * per_sample);
+    const f32x4* s = reinterpret_cast<const f32x4*>(src + (size_t)b * per_sample);
+    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) d[i] = s[i];
+}
+
+__global__ void rows_zero_kernel(__bf16* __restrict__ x, const uint8_t* __restrict__ keep, long long per_sample) {
+    const int b = blockIdx.y;
+    if (keep[b]) return;
+    const long long slab = (per_sample / 8 + ROWFIX_SLABS - 1) / ROWFIX_SLABS;
+    const long long lo = (long long)blockIdx.x * slab, hi = lo + slab < per_sample / 8 ? lo + slab : per_sample / 8;
+    bf16x8* d = reinterpret_cast<bf16x8*>(x + (size_t)b * per_sample);
+    const bf16x8 z = {};
+    for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) d[i] = z;
+}
+
+/* dst[b] = src[b] for every sample b with keep[b] == 0; dst, src [B, per_sample] f32, per_sample % 4 == 0 */
+extern "C" int p4p_rows_restore_f32(float* dst, const float* src, const uint8_t* keep, int B, long long per_sample,
+                                    void* stream) {
+    P4P_CHECK(dst && src && keep, "p4p_rows_restore_f32: null pointer");
+    P4P_CHECK(B >= 1 && B <= 65535 && per_sample >= 4 && per_sample % 4 == 0, "p4p_rows_restore_f32: bad sizes B=%d per_sample=%lld",
+              B, per_sample);
+    hipLaunchKernelGGL(rows_restore_kernel, dim3(ROWFIX_SLABS, B), dim3(256), 0, (hipStream_t)stream, dst, src, keep, per_sample);
+    P4P_LAUNCH_CHECK();
+    return 0;
+}
+
+/* x[b] = 0 for every sample b with keep[b] == 0; x [B, per_sample] bf16, per_sample % 8 == 0 */
+extern "C" int p4p_rows_zero_bf16(void* x, const uint8_t* keep, int B, long long per_sample, void* stream) {
+    P4P_CHECK(x && keep, "p4p_rows_zero_bf16: null pointer");
+    P4P_CHECK(B >= 1 && B <= 65535 && per_sample >= 8 && per_sample % 8 == 0, "p4p_rows_zero_bf16: bad sizes B=%d per_sample=%lld", B,
+              per_sample);
+    hipLaunchKernelGGL(rows_zero_kernel, dim3(ROWFIX_SLABS, B), dim3(256), 0, (hipStream_t)stream, (__bf16*)x, keep, per_sample);
+    P4P_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// AdapterLayer bottleneck (apf_utils.py:222-226): down = dropout(relu(pre)) on the [M, 64] tensor between the two adapter
+// GEMMs, as one launch each way.  u (may be NULL) = uniform [0,1) draws for the dropout (kept where u >= p, scaled by
+// 1/(1-p)); gate = relu'(pre) * dropout factor is what the backward multiplies by.
+// ---------------------------------------------------------------------------------------------
+__global__ void adapter_mid_fwd_kernel(const float* __restrict__ pre, const float* __restrict__ u, float p, float inv_keep,
+                                       __bf16* __restrict__ down, float* __restrict__ gate, long long n) {
+    const long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (e >= n) return;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(pre + e);
+    f32x4 g;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g[i] = v[i] > 0.f ? 1.f : 0.f;
+    if (u) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(u + e);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = r[i] >= p ? g[i] * inv_keep : 0.f;
+    }
+    const bf16x4 o = {f2bf(v[0] * g[0]), f2bf(v[1] * g[1]), f2bf(v[2] * g[2]), f2bf(v[3] * g[3])};
+    *reinterpret_cast<bf16x4*>(down + e) = o;
+    *reinterpret_cast<f32x4*>(gate + e) = g;
+}
+
+__global__ void adapter_mid_bwd_kernel(const float* __restrict__ ddown, const float* __restrict__ gate,
+                                       __bf16* __restrict__ dpre, long long n) {
+    const long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (e >= n) return;
+    const f32x4 d = *reinterpret_cast<const f32x4*>(ddown + e), g = *reinterpret_cast<const f32x4*>(gate + e);
+    const bf16x4 o = {f2bf(d[0] * g[0]), f2bf(d[1] * g[1]), f2bf(d[2] * g[2]), f2bf(d[3] * g[3])};
+    *reinterpret_cast<bf16x4*>(dpre + e) = o;
+}
+
+extern "C" int p4p_adapter_mid_fwd(const float* pre, const float* u, float p, void* down_bf16, float* gate, long long n,
+                                   void* stream) {
+    P4P_CHECK(pre && down_bf16 && gate, "p4p_adapter_mid_fwd: null pointer");
+    P4P_CHECK(n >= 4 && n % 4 == 0 && p >= 0.f && p < 1.f, "p4p_adapter_mid_fwd: bad arguments n=%lld p=%f", n, (double)p);
+    hipLaunchKernelGGL(adapter_mid_fwd_kernel, dim3(ceil_div(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, pre,
+                       p > 0.f ? u : nullptr, p, 1.f / (1.f - p), (__bf16*)down_bf16, gate, n);
+    P4P_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int p4p_adapter_mid_bwd(const float* ddown, const float* gate, void* dpre_bf16, long long n, void* stream) {
+    P4P_CHECK(ddown && gate && dpre_bf16, "p4p_adapter_mid_bwd: null pointer");
+    P4P_CHECK(n >= 4 && n % 4 == 0, "p4p_adapter_mid_bwd: bad size n=%lld", n);
+    hipLaunchKernelGGL(adapter_mid_bwd_kernel, dim3(ceil_div(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, ddown, gate,
+                       (__bf16*)dpre_bf16, n);
     P4P_LAUNCH_CHECK();
     return 0;
 }

@@ -228,18 +228,23 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* 
     save_invstd[c] = invstd;
 }
 
-// y = relu(scale[c] * x + shift[c]), bf16 -> bf16, [rows, C], C % 4 == 0
+// y = relu(scale[c] * x + shift[c]), bf16 -> bf16, [rows, C], C % 4 == 0; V = 4 or 8 elements per thread
+template <int V>
 __global__ void bn_relu_bf16_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y, const float* __restrict__ scale,
                                     const float* __restrict__ shift, long long n, int C) {
-    long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    typedef __attribute__((ext_vector_type(V))) __bf16 bvec;
+    long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (e >= n) return;
     const int c = (int)(e % C);
-    bf16x4 w = *reinterpret_cast<const bf16x4*>(x + e);
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
-    bf16x4 o;
+    const bvec w = *reinterpret_cast<const bvec*>(x + e);
+    bvec o;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) o[i] = f2bf(fmaxf(sc[i] * bf2f(w[i]) + sh[i], 0.f));
-    *reinterpret_cast<bf16x4*>(y + e) = o;
+    for (int q = 0; q < V; q += 4) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c + q), sh = *reinterpret_cast<const f32x4*>(shift + c + q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[q + i] = f2bf(fmaxf(sc[i] * bf2f(w[q + i]) + sh[i], 0.f));
+    }
+    *reinterpret_cast<bvec*>(y + e) = o;
 }
 
 // tokens[g][c] = max_j relu(scale*H3[g*k+j][c] + shift); thread = (g, channel quad)
@@ -354,9 +359,10 @@ __global__ void pool_bn_bwd_apply_kernel(const void* __restrict__ dtok, int dtok
 }
 
 // ---------------------------------------------------------------------------------------------
-// backward B3/B4: ReLU + BN over a dense [rows, C] gradient.  dy is masked IN PLACE.
+// backward B3/B4: ReLU + BN over a dense [rows, C] gradient.  The statistics pass only reads; the apply pass re-derives the
+// ReLU mask from H and rewrites dY in place (one write of the gradient instead of two).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void relu_bn_bwd_stats_kernel(__bf16* __restrict__ dY, const __bf16* __restrict__ H,
+__global__ __launch_bounds__(256) void relu_bn_bwd_stats_kernel(const __bf16* __restrict__ dY, const __bf16* __restrict__ H,
                                                                 const float* __restrict__ scale,
                                                                 const float* __restrict__ shift,
                                                                 const float* __restrict__ mean,
@@ -374,17 +380,15 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_stats_kernel(__bf16* __restri
         const long long r_end = r_begin + rows_per_block < rows ? r_begin + rows_per_block : rows;
         for (long long r = r_begin + ty; r < r_end; r += 4) {
             const size_t o = (size_t)r * C + c;
-            bf16x4 d = *reinterpret_cast<const bf16x4*>(dY + o);
+            const bf16x4 d = *reinterpret_cast<const bf16x4*>(dY + o);
             const bf16x4 h = *reinterpret_cast<const bf16x4*>(H + o);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float hv = bf2f(h[i]);
-                const float dy = (sc[i] * hv + sh[i] > 0.f) ? bf2f(d[i]) : 0.f;
-                d[i] = f2bf(dy);
+                const float dy = (sc[i] * hv + sh[i] > 0.f) ? bf2f(d[i]) : 0.f;     // the apply pass re-derives the mask
                 s0[i] += dy;
                 s1[i] += dy * (hv - mu[i]) * is[i];
             }
-            *reinterpret_cast<bf16x4*>(dY + o) = d;
         }
     }
     red[0][ty][tx] = s0; red[1][ty][tx] = s1;
@@ -397,24 +401,32 @@ __global__ __launch_bounds__(256) void relu_bn_bwd_stats_kernel(__bf16* __restri
     }
 }
 
-// dH = gamma*invstd*(dy - sums[0]/Np - xhat*sums[1]/Np), in place over dY
+// dH = gamma*invstd*(relu'(y) dy - sums[0]/Np - xhat*sums[1]/Np), in place over dY; V = 4 or 8 elements per thread
+template <int V>
 __global__ void bn_bwd_apply_kernel(__bf16* __restrict__ dY, const __bf16* __restrict__ H,
-                                    const float* __restrict__ scale, const float* __restrict__ mean,
-                                    const float* __restrict__ invstd, const float* __restrict__ sums, float invNp,
-                                    long long n, int C) {
-    long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ sums, float invNp, long long n, int C) {
+    typedef __attribute__((ext_vector_type(V))) __bf16 bvec;
+    long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (e >= n) return;
     const int c = (int)(e % C);
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
-    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
-    const f32x4 m1 = *reinterpret_cast<const f32x4*>(sums + c) * invNp;
-    const f32x4 m2 = *reinterpret_cast<const f32x4*>(sums + C + c) * invNp;
-    bf16x4 d = *reinterpret_cast<const bf16x4*>(dY + e);
-    const bf16x4 h = *reinterpret_cast<const bf16x4*>(H + e);
+    bvec d = *reinterpret_cast<const bvec*>(dY + e);
+    const bvec h = *reinterpret_cast<const bvec*>(H + e);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        d[i] = f2bf(sc[i] * (bf2f(d[i]) - m1[i] - (bf2f(h[i]) - mu[i]) * is[i] * m2[i]));
-    *reinterpret_cast<bf16x4*>(dY + e) = d;
+    for (int q = 0; q < V; q += 4) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c + q), sh = *reinterpret_cast<const f32x4*>(shift + c + q);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c + q), is = *reinterpret_cast<const f32x4*>(invstd + c + q);
+        const f32x4 m1 = *reinterpret_cast<const f32x4*>(sums + c + q) * invNp;
+        const f32x4 m2 = *reinterpret_cast<const f32x4*>(sums + C + c + q) * invNp;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float hv = bf2f(h[q + i]);
+            const float dy = (sc[i] * hv + sh[i] > 0.f) ? bf2f(d[q + i]) : 0.f;
+            d[q + i] = f2bf(sc[i] * (dy - m1[i] - (hv - mu[i]) * is[i] * m2[i]));
+        }
+    }
+    *reinterpret_cast<bvec*>(dY + e) = d;
 }
 
 // out[g][c] = sum_j X[g*k+j][c]   (bf16 in, bf16 out, fp32 sum)
@@ -629,8 +641,12 @@ extern "C" int p4p_bn_relu_bf16(const void* x, void* y, const float* scale, cons
                                 void* stream) {
     P4P_CHECK(x && y && scale && shift && rows >= 1 && C % 4 == 0, "p4p_bn_relu_bf16: bad arguments");
     long long n = rows * C;
-    hipLaunchKernelGGL(bn_relu_bf16_kernel, dim3(ceil_div(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const __bf16*)x, (__bf16*)y, scale, shift, n, C);
+    if (C % 8 == 0)
+        hipLaunchKernelGGL(bn_relu_bf16_kernel<8>, dim3(ceil_div(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const __bf16*)x, (__bf16*)y, scale, shift, n, C);
+    else
+        hipLaunchKernelGGL(bn_relu_bf16_kernel<4>, dim3(ceil_div(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const __bf16*)x, (__bf16*)y, scale, shift, n, C);
     P4P_LAUNCH_CHECK();
     return 0;
 }
@@ -676,13 +692,17 @@ extern "C" int p4p_relu_bn_bwd(void* dY, const void* H, const float* scale, cons
     int nb = (int)(rows < EMBED_BLOCKS ? rows : EMBED_BLOCKS);
     int rpb = (int)((rows + nb - 1) / nb);
     nb = (int)((rows + rpb - 1) / rpb);
-    hipLaunchKernelGGL(relu_bn_bwd_stats_kernel, dim3(ceil_div(C, 256), nb), dim3(256), 0, st, (__bf16*)dY,
+    hipLaunchKernelGGL(relu_bn_bwd_stats_kernel, dim3(ceil_div(C, 256), nb), dim3(256), 0, st, (const __bf16*)dY,
                        (const __bf16*)H, scale, shift, mean, invstd, partial, rows, C, rpb);
     P4P_LAUNCH_CHECK();
     if (p4p_colreduce_f32(partial, sums, nb, (long long)2 * C, 2 * C, 0.f, stream)) return 2;
     long long n = rows * C;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ceil_div(n / 4, 256)), dim3(256), 0, st, (__bf16*)dY, (const __bf16*)H,
-                       scale, mean, invstd, sums, (float)(1.0 / (double)rows), n, C);
+    if (C % 8 == 0)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<8>, dim3(ceil_div(n / 8, 256)), dim3(256), 0, st, (__bf16*)dY,
+                           (const __bf16*)H, scale, shift, mean, invstd, sums, (float)(1.0 / (double)rows), n, C);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ceil_div(n / 4, 256)), dim3(256), 0, st, (__bf16*)dY,
+                           (const __bf16*)H, scale, shift, mean, invstd, sums, (float)(1.0 / (double)rows), n, C);
     P4P_LAUNCH_CHECK();
     return 0;
 }

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(const void* _
             const int c = j * 256 + lane * 4;
             if (c < D) {
                 f32x4 o = (d[j] * g[j] - m1 - xh[j] * m2) * rs;
-                if (accumulate) o += *reinterpret_cast<const f32x4*>(dx + base + c);
+                if (accumulate) o += (float)accumulate * *reinterpret_cast<const f32x4*>(dx + base + c);   // 1 or 2 (a residual used twice)
                 *reinterpret_cast<f32x4*>(dx + base + c) = o;
                 ao[j] += o;
                 if (dx_bf16) {

@@ -31,6 +31,33 @@ def _bn_after_bias(bn, scale, shift, bias, training):
     return shift + scale * bias.detach()
 
 
+def _scaled_operands(w, b, c):
+    """bf16 (c W, (c W)^T) and fp32 c b of a FROZEN Linear, cached on the weight (DropPath's 1/keep lives in the weights)."""
+    cache = getattr(w, '_p4p_scaled', None)
+    if cache is None:
+        cache = {}
+        w._p4p_scaled = cache
+    ent = cache.get(c)
+    if ent is None or ent[0] != (w._version, b._version, w.data_ptr()):
+        wb, wt = ops.cast_weight(w.detach() * c, True, True)
+        ent = ((w._version, b._version, w.data_ptr()), wb, wt, b.detach() * c)
+        cache[c] = ent
+    return ent[1], ent[2], ent[3]
+
+
+def _adapter_up_operands(uw, ub, scale):
+    """bf16 (s W_up, (s W_up)^T) and fp32 s b_up of the adapter's up-projection with its `scale` folded in
+    (apf_utils.py:228-230), cached on the weight until any of the three tensors changes."""
+    key = (uw._version, ub._version, scale._version, uw.data_ptr())
+    ent = getattr(uw, '_p4p_up', None)
+    if ent is None or ent[0] != key:
+        sc = scale.detach().reshape(())
+        wb, wt = ops.cast_weight(uw.detach() * sc, True, True)
+        ent = (key, wb, wt, ub.detach() * sc)
+        uw._p4p_up = ent
+    return ent[1], ent[2], ent[3]
+
+
 def _split_hi_lo_weight(W1):
     """[C,6] fp32 -> bf16 [C,64] = [W_hi, W_hi, W_lo, 0]: partner of the x0 layout of p4p_apf_group."""
     C = W1.shape[0]
@@ -163,11 +190,13 @@ def apf_block_params(blk):
 
 class _ApfBlocksFn(torch.autograd.Function):
     """x f32 [B,T,D] -> L blocks -> optional final LayerNorm.  Per block (apf_utils.py:277-293):
-        x1  = x + s_a * attention(norm1(x))
+        x1  = x + keep_a/q * attention(norm1(x))
         r   = up(drop(relu(down(adapter_norm(x1))))) * scale + 2 * x1       (adapter output + the block's own residual)
-        out = s_m * mlp(norm2(x1)) + r
-    s_a / s_m are the per-sample DropPath factors (None = identity).  The up-projection GEMM writes r directly (two
-    residual inputs), the fc2 GEMM adds r in its epilogue: no elementwise pass exists on the deterministic path."""
+        out = keep_m/q * mlp(norm2(x1)) + r
+    keep_a / keep_m are the per-sample DropPath draws (bool [B], None = identity), q the keep probability; drop_masks[l] =
+    (keep_a, keep_m, 1/q).  The up-projection GEMM writes r directly (two residual inputs), the proj / fc2 GEMMs add their
+    residual in the epilogue with 1/q folded into the frozen weights; the dropped samples' rows are then put back
+    (p4p_rows_restore_f32): no elementwise pass over the stream exists on this path."""
 
     @staticmethod
     def forward(ctx, x, num_heads, eps, train, drop_masks, adapter_p, norm_w, norm_b, *bp):
@@ -179,29 +208,25 @@ class _ApfBlocksFn(torch.autograd.Function):
         for l in range(L):
             (n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, anw, anb, ascale, dw, db, uw,
              ub) = bp[l * _APF_BLOCK_PARAMS:(l + 1) * _APF_BLOCK_PARAMS]
-            s_a, s_m = drop_masks[l] if drop_masks is not None else (None, None)
+            keep_a, keep_m, c = drop_masks[l] if drop_masks is not None else (None, None, 1.0)
             xin = x
             ln1, _, mean1, rstd1 = ops.layernorm_fwd(xin, n1w.detach(), n1b.detach(), eps, want_stats=train)
             Wqkv, _ = _bf16_weights(qkvw, train)
             qkv = ops.gemm_tn(ln1, Wqkv, ops.EPI_BF16, bias=qkvb.detach())
             att, lse = ops.attention_fwd(qkv, B, T, H, want_lse=train)
-            Wproj, _ = _bf16_weights(projw, train)
-            if s_a is None:
+            if keep_a is None:
+                Wproj, _ = _bf16_weights(projw, train)
                 x1 = ops.gemm_tn(att, Wproj, ops.EPI_F32_RESID, bias=projb.detach(), resid=xin)
-            else:
-                y = ops.gemm_tn(att, Wproj, ops.EPI_F32_RESID, bias=projb.detach())
-                x1 = torch.addcmul(xin.view(B, T, D), y.view(B, T, D), s_a.view(B, 1, 1)).view(M, D)
+            else:               # DropPath: weights carry 1/keep, dropped samples get their residual back
+                Wproj, _, bproj = _scaled_operands(projw, projb, c)
+                x1 = ops.rows_restore_(ops.gemm_tn(att, Wproj, ops.EPI_F32_RESID, bias=bproj, resid=xin), xin, keep_a, B)
             # ---- adapter (apf_utils.py:217-233)
             aln, _, meanA, rstdA = ops.layernorm_fwd(x1, anw.detach(), anb.detach(), eps, want_stats=train)
             Wd, _ = _bf16_weights(dw, train)
             pre = ops.gemm_tn(aln, Wd, ops.EPI_F32_RESID, bias=db.detach())        # [M, 64] f32
-            dmask = (pre > 0).to(torch.float32)
-            if adapter_p > 0:
-                dmask = dmask * (torch.rand_like(pre) >= adapter_p).to(torch.float32) / (1.0 - adapter_p)
-            down = (pre * dmask).bfloat16()
-            sc = ascale.detach().reshape(())
-            Wu = (uw.detach() * sc).bfloat16()                                     # [D, 64], scale folded in
-            r = ops.gemm_tn(down, Wu, ops.EPI_F32_RESID, bias=ub.detach() * sc, resid=x1, resid2=x1)
+            down, dmask = ops.adapter_mid_fwd(pre, adapter_p)
+            Wu, WuT, bu = _adapter_up_operands(uw, ub, ascale)                     # [D, 64] with `scale` folded in
+            r = ops.gemm_tn(down, Wu, ops.EPI_F32_RESID, bias=bu, resid=x1, resid2=x1)
             # ---- mlp
             ln2, _, mean2, rstd2 = ops.layernorm_fwd(x1, n2w.detach(), n2b.detach(), eps, want_stats=train)
             Wfc1, _ = _bf16_weights(fc1w, train)
@@ -209,15 +234,15 @@ class _ApfBlocksFn(torch.autograd.Function):
                 g, hpre = ops.gemm_tn(ln2, Wfc1, ops.EPI_BF16_GELU, bias=fc1b.detach(), want_pre=True)
             else:
                 g, hpre = ops.gemm_tn(ln2, Wfc1, ops.EPI_BF16_GELU, bias=fc1b.detach()), None
-            Wfc2, _ = _bf16_weights(fc2w, train)
-            if s_m is None:
+            if keep_m is None:
+                Wfc2, _ = _bf16_weights(fc2w, train)
                 x = ops.gemm_tn(g, Wfc2, ops.EPI_F32_RESID, bias=fc2b.detach(), resid=r)
             else:
-                y = ops.gemm_tn(g, Wfc2, ops.EPI_F32_RESID, bias=fc2b.detach())
-                x = torch.addcmul(r.view(B, T, D), y.view(B, T, D), s_m.view(B, 1, 1)).view(M, D)
+                Wfc2, _, bfc2 = _scaled_operands(fc2w, fc2b, c)
+                x = ops.rows_restore_(ops.gemm_tn(g, Wfc2, ops.EPI_F32_RESID, bias=bfc2, resid=r), r, keep_m, B)
             if train:
-                saved += [xin, mean1, rstd1, qkv, att, lse, x1, meanA, rstdA, dmask, Wu.t().contiguous(), mean2, rstd2, hpre]
-                scal.append((s_a, s_m))
+                saved += [xin, mean1, rstd1, qkv, att, lse, x1, meanA, rstdA, dmask, WuT, mean2, rstd2, hpre]
+                scal.append((keep_a, keep_m, c))
         if norm_w is not None:
             y, _, meanN, rstdN = ops.layernorm_fwd(x, norm_w.detach(), norm_b.detach(), eps, out_f32=True, want_stats=train)
         else:
@@ -250,32 +275,36 @@ class _ApfBlocksFn(torch.autograd.Function):
             dx = dy.reshape(M, D).contiguous().float().clone()
             dxb.copy_(dx)
 
-        def scaled(s):                                                            # bf16 rows of dx times the DropPath factor
-            return dxb if s is None else (dx.view(B, T, D) * s.view(B, 1, 1)).to(torch.bfloat16).view(M, D)
-
         NS = 14
         for l in reversed(range(L)):
             (n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b, anw, anb, ascale, dw, db, uw,
              ub) = bp[l * _APF_BLOCK_PARAMS:(l + 1) * _APF_BLOCK_PARAMS]
             xin, mean1, rstd1, qkv, att, lse, x1, meanA, rstdA, dmask, WuT, mean2, rstd2, hpre = saved[l * NS:(l + 1) * NS]
-            s_a, s_m = ctx.scal[l]
+            keep_a, keep_m, c = ctx.scal[l]
             # ---- mlp branch
-            _, Wfc2T = _bf16_weights(fc2w, True)
-            dh = ops.gemm_tn(scaled(s_m), Wfc2T, ops.EPI_BF16_DGELU, pre=hpre)
+            if keep_m is None:
+                _, Wfc2T = _bf16_weights(fc2w, True)
+                dh = ops.gemm_tn(dxb, Wfc2T, ops.EPI_BF16_DGELU, pre=hpre)
+            else:
+                _, Wfc2T, _ = _scaled_operands(fc2w, fc2b, c)
+                dh = ops.rows_zero_(ops.gemm_tn(dxb, Wfc2T, ops.EPI_BF16_DGELU, pre=hpre), keep_m, B)
             _, Wfc1T = _bf16_weights(fc1w, True)
             dln2 = ops.gemm_tn(dh, Wfc1T, ops.EPI_BF16)
             del dh
             # ---- adapter branch: r = up(down) + 2 x1
             ddown = ops.gemm_tn(dxb, WuT, ops.EPI_F32_RESID)                       # [M, 64] f32
-            dpre = (ddown * dmask).bfloat16()
+            dpre = ops.adapter_mid_bwd(ddown, dmask)
             _, WdT = _bf16_weights(dw, True)
             daln = ops.gemm_tn(dpre, WdT, ops.EPI_BF16)
-            dx.mul_(2.0)
-            ops.layernorm_bwd(dln2, x1, mean2, rstd2, n2w.detach(), dx=dx)
+            ops.layernorm_bwd(dln2, x1, mean2, rstd2, n2w.detach(), dx=dx, dx_factor=2)     # r = ... + 2 x1
             ops.layernorm_bwd(daln, x1, meanA, rstdA, anw.detach(), dx=dx, dx_bf16=dxb)
             # ---- attention branch
-            _, WprojT = _bf16_weights(projw, True)
-            datt = ops.gemm_tn(scaled(s_a), WprojT, ops.EPI_BF16)
+            if keep_a is None:
+                _, WprojT = _bf16_weights(projw, True)
+                datt = ops.gemm_tn(dxb, WprojT, ops.EPI_BF16)
+            else:
+                _, WprojT, _ = _scaled_operands(projw, projb, c)
+                datt = ops.rows_zero_(ops.gemm_tn(dxb, WprojT, ops.EPI_BF16), keep_a, B)
             dqkv = ops.attention_bwd(qkv, att, datt, lse, B, T, H)
             _, WqkvT = _bf16_weights(qkvw, True)
             dln1 = ops.gemm_tn(dqkv, WqkvT, ops.EPI_BF16)
@@ -285,7 +314,7 @@ class _ApfBlocksFn(torch.autograd.Function):
 
 
 def apf_blocks(x, blocks, norm, num_heads, drop_masks=None, adapter_p=0.0):
-    """blocks: iterable of APFViTLayer; norm: LayerNorm or None; drop_masks: per block (s_attn, s_mlp) of shape (B,) or None."""
+    """blocks: iterable of APFViTLayer; norm: LayerNorm or None; drop_masks: per block (keep_attn, keep_mlp, 1/keep_prob) with bool (B,) draws, or None."""
     bp = []
     for blk in blocks:
         bp += apf_block_params(blk)

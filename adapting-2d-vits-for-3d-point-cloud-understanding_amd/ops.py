@@ -169,14 +169,16 @@ def layernorm_fwd(x, gamma, beta, eps=1e-6, pos=None, want_sum=False, out_f32=Fa
 
 
 def layernorm_bwd(dy, xin, mean, rstd, gamma, dx=None, dgamma=None, dbeta=None, beta_acc=0.0, dx_bf16=None,
-                  dacc=None, dacc_init=False, want_dxsum=False):
-    """Returns (dx, dgamma, dbeta); if dx is given the LN gradient is ADDED to it in place.  dx_bf16 gets a
-    bf16 copy of the result, dacc accumulates it (positional-embedding gradient)."""
+                  dacc=None, dacc_init=False, want_dxsum=False, dx_factor=1):
+    """Returns (dx, dgamma, dbeta); if dx is given the LN gradient is ADDED to dx_factor * dx in place (dx_factor 1 or 2).
+    dx_bf16 gets a bf16 copy of the result, dacc accumulates it (positional-embedding gradient)."""
     M, D = xin.shape
     _chk(dy, 'dy', None, 2)
     if dy.dtype not in (torch.float32, torch.bfloat16):
         raise RuntimeError('layernorm_bwd: dy must be f32 or bf16')
     acc = dx is not None
+    if dx_factor not in (1, 2):
+        raise RuntimeError('layernorm_bwd: dx_factor must be 1 or 2')
     if dx is None:
         dx = torch.empty(M, D, dtype=torch.float32, device=xin.device)
     dxsum = None
@@ -187,7 +189,7 @@ def layernorm_bwd(dy, xin, mean, rstd, gamma, dx=None, dgamma=None, dbeta=None, 
     rows = L.call_int('p4p_layernorm_bwd_partial_rows')
     part = _workspace('lnbwd', rows * 3 * D, xin.device)
     L.call('p4p_layernorm_bwd', L.ptr(dy), int(dy.dtype == torch.float32), L.ptr(xin), L.ptr(mean), L.ptr(rstd),
-           L.ptr(gamma), L.ptr(dx), int(acc), L.ptr(dx_bf16), L.ptr(dacc), int(dacc_init), L.ptr(part), L.ptr(dgamma),
+           L.ptr(gamma), L.ptr(dx), int(dx_factor) if acc else 0, L.ptr(dx_bf16), L.ptr(dacc), int(dacc_init), L.ptr(part), L.ptr(dgamma),
            L.ptr(dbeta), L.ptr(dxsum), float(beta_acc), M, D, _stream())
     if want_dxsum:
         return dx, dgamma, dbeta, dxsum
@@ -484,3 +486,42 @@ def group_max_bwd(dtok, arg, G, k, into=None):
     L.call('p4p_group_max_bwd', L.ptr(dtok), int(dtok.dtype == torch.float32), L.ptr(arg), L.ptr(dH), int(into is not None),
            L.i64(G), int(k), C, _stream())
     return dH
+
+
+def rows_restore_(dst, src, keep, B):
+    """dst[b] = src[b] for the samples with keep[b] == False (dst, src f32, B samples of equal size; keep bool [B])."""
+    _chk(dst, 'dst', torch.float32)
+    _chk(src, 'src', torch.float32)
+    _chk(keep, 'keep', torch.bool, 1)
+    if dst.shape != src.shape or dst.numel() % B or keep.shape[0] != B:
+        raise RuntimeError('rows_restore_: shapes do not match')
+    L.call('p4p_rows_restore_f32', L.ptr(dst), L.ptr(src), L.ptr(keep), B, L.i64(dst.numel() // B), _stream())
+    return dst
+
+
+def rows_zero_(x, keep, B):
+    """x[b] = 0 for the samples with keep[b] == False (x bf16, B samples of equal size; keep bool [B])."""
+    _chk(x, 'x', torch.bfloat16)
+    _chk(keep, 'keep', torch.bool, 1)
+    if x.numel() % B or keep.shape[0] != B:
+        raise RuntimeError('rows_zero_: shapes do not match')
+    L.call('p4p_rows_zero_bf16', L.ptr(x), L.ptr(keep), B, L.i64(x.numel() // B), _stream())
+    return x
+
+
+def adapter_mid_fwd(pre, p=0.0):
+    """(down bf16, gate f32) = dropout_p(relu(pre)) and its derivative factor (reference src/models/apf_utils.py:222-226)."""
+    _chk(pre, 'pre', torch.float32, 2)
+    u = torch.rand_like(pre) if p > 0 else None
+    down = torch.empty(pre.shape, dtype=torch.bfloat16, device=pre.device)
+    gate = torch.empty_like(pre)
+    L.call('p4p_adapter_mid_fwd', L.ptr(pre), L.ptr(u), float(p), L.ptr(down), L.ptr(gate), L.i64(pre.numel()), _stream())
+    return down, gate
+
+
+def adapter_mid_bwd(ddown, gate):
+    _chk(ddown, 'ddown', torch.float32, 2)
+    _chk(gate, 'gate', torch.float32, 2)
+    dpre = torch.empty(ddown.shape, dtype=torch.bfloat16, device=ddown.device)
+    L.call('p4p_adapter_mid_bwd', L.ptr(ddown), L.ptr(gate), L.ptr(dpre), L.i64(ddown.numel()), _stream())
+    return dpre

@@ -31,6 +31,15 @@ def flop_per_cloud(points, D, L, k=16):
     return 3.0 * (S * k * 920576.0 + L * (24.0 * T * D * D + 4.0 * T * T * D))
 
 
+def apf_flop_per_cloud(G=196, gs=32, E=768, L=12, bottleneck=64):
+    """fwd+bwd algorithmic FLOPs per cloud of the APF path (BASELINE.json configs[3]).  Encoder as the reference computes
+    it (src/models/apf.py:129-143: every point meets the full 2E x 2E layer), trainable => 3x forward; transformer with
+    T = G tokens and the bottleneck adapter, frozen (apf.py:335-346) => forward + input gradient = 2x forward."""
+    enc = G * gs * 2.0 * (6 * 256 + 256 * 512 + 512 * E + 2 * E * 2 * E + 2 * E * E)
+    vit = L * (24.0 * G * E * E + 4.0 * G * G * E + 4.0 * G * E * bottleneck)
+    return 3.0 * enc + 2.0 * vit
+
+
 def log(msg):
     print(f'[bench] {msg}', file=sys.stderr, flush=True)
 
@@ -102,6 +111,38 @@ class Stepper:
         else:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=10, foreach=True)
             self.opt.step()
+        return loss
+
+
+class ApfStepper:
+    """One APF training step as the reference's APFTrainer runs it (src/train/apf_trainer.py:164-171,260-275): zero_grad,
+    forward (train mode: DropPath, adapter / head dropout, batch-statistics BatchNorm), CrossEntropy with label smoothing
+    0.3, backward, AdamW over model.parameters() (no gradient clipping on this path)."""
+
+    def __init__(self, args, device, distributed):
+        import contextlib
+        import p4p_amd
+        from p4p_amd.ddp import GradReducer, broadcast_parameters
+        from p4p_amd.optim import FusedAdamW
+        torch.manual_seed(1234)
+        with contextlib.redirect_stdout(sys.stderr):
+            self.model = p4p_amd.AdaptPointFormer(num_classes=args.classes, vit_name=args.vit, pretrained=False).to(device)
+        self.model.train()
+        broadcast_parameters(self.model)
+        self.reducer = GradReducer([[p for p in self.model.parameters() if p.requires_grad]]) if distributed else None
+        self.opt = FusedAdamW(self.model.parameters(), lr=5e-4, weight_decay=5e-2)
+        self.crit = torch.nn.CrossEntropyLoss(label_smoothing=0.3)
+
+    def step(self, pts, labels, start):
+        if self.reducer is not None:
+            self.reducer.zero_grad()
+        else:
+            self.opt.zero_grad(set_to_none=True)
+        loss = self.crit(self.model(pts, start), labels)
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.opt.step()
         return loss
 
 
@@ -192,14 +233,23 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=256, help='clouds per GPU')
-    ap.add_argument('--points', type=int, default=1024)
-    ap.add_argument('--vit', default='vit_base_patch16_384')
+    ap.add_argument('--workload', choices=('pix4point', 'apf'), default='pix4point',
+                    help='pix4point = BASELINE.json configs[1] (the contract line); apf = configs[3], the adapter path')
+    ap.add_argument('--batch', type=int, default=None, help='clouds per GPU (default 256; apf: 128)')
+    ap.add_argument('--points', type=int, default=None, help='points per cloud (default 1024; apf: 2048)')
+    ap.add_argument('--vit', default=None)
     ap.add_argument('--dim', type=int, default=768)
-    ap.add_argument('--classes', type=int, default=40)
+    ap.add_argument('--classes', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
+    apf = args.workload == 'apf'
+    args.batch = args.batch or (128 if apf else 256)
+    args.points = args.points or (2048 if apf else 1024)
+    args.vit = args.vit or ('vit_base_patch16_224' if apf else 'vit_base_patch16_384')
+    args.classes = args.classes or (15 if apf else 40)
+    if apf:
+        args.no_cpu_baseline = True        # the CPU leg of this file times the Pix4Point oracle (the contract workload)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -213,7 +263,7 @@ def main():
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
 
-    stepper = Stepper(args, device, distributed)
+    stepper = (ApfStepper if apf else Stepper)(args, device, distributed)
     batch = synthetic_batch(args.batch, args.points, args.classes, 1234 + rank, device)
 
     log(f'rank {rank}/{world}: model built, warm-up {args.warmup} steps')
@@ -253,7 +303,7 @@ def main():
         value = clouds / elapsed
         from p4p_amd.vit import parse_model_name
         vd, vl, vh, _, _ = parse_model_name(args.vit)
-        fl = flop_per_cloud(args.points, vd, vl)
+        fl = apf_flop_per_cloud(E=vd, L=vl) if apf else flop_per_cloud(args.points, vd, vl)
         fam = {192: 'ViT-Ti', 384: 'ViT-S', 768: 'ViT-B', 1024: 'ViT-L'}.get(vd, f'ViT(D={vd})')
         out = {
             'metric': f'point-clouds/sec fwd+bwd (train step), ModelNet40-shaped N={args.points} {fam}',
@@ -268,6 +318,13 @@ def main():
             'algorithmic_tflops_per_gpu': (value / world * fl * 1e-12) if fl else None,
             'mfma_frac_whole_step': (value / world * fl * 1e-12 / PEAK_BF16_TFLOPS) if fl else None,
         }
+        if apf:
+            out['metric'] = f'point-clouds/sec fwd+bwd (train step), APF adapter path N={args.points} {fam} frozen'
+            out['config']['workload'] = (f'AdaptPointFormer {args.vit} (D={vd}, {vl} frozen blocks + adapters), 196 groups of 32, '
+                                         f'N={args.points}, {args.classes} classes, batch {args.batch}/GPU; step = zero_grad+fwd+'
+                                         f'CE(ls 0.3)+bwd{"+RCCL all-reduce" if distributed else ""}+AdamW(fused), train-mode '
+                                         'DropPath/dropout; FLOP model: encoder 3x fwd as the reference computes it, frozen '
+                                         'transformer 2x fwd')
         if roof:
             out['roofline'] = roof
         if cpu:

@@ -74,7 +74,8 @@ int p4p_wgrad_splits(int M, int N, int K);
  * (the `feats + pos_embed` of src/models/pix4point.py:255); y bf16 or f32; mean/rstd [M] (may be NULL). */
 int p4p_layernorm_fwd(const float* x, const float* pos, const float* gamma, const float* beta, float eps,
                       float* xsum, void* y, int y_is_f32, float* mean, float* rstd, int M, int D, void* stream);
-/* dx = (accumulate_dx ? dx : 0) + LN'(dy); dgamma/dbeta = beta_acc*old + sums (either may be NULL);
+/* dx = accumulate_dx * dx + LN'(dy) with accumulate_dx in {0, 1, 2} (2: the residual stream enters its block twice,
+ * src/models/apf_utils.py:232,292); dgamma/dbeta = beta_acc*old + sums (either may be NULL);
  * dxsum (may be NULL) = beta_acc*old + column sums of the resulting dx: the bias gradient of the Linear that wrote
  * this residual stream (proj.bias / fc2.bias), free of an extra pass.
  * dx_bf16 (may be NULL) receives a bf16 copy of dx (next GEMM operand); dacc (may be NULL) accumulates dx
@@ -204,6 +205,17 @@ int p4p_group_max_bf16(const void* H, const float* bias, float* tok_f32, void* t
                        int C, void* stream);
 int p4p_group_max_bwd(const void* dtok, int dtok_is_f32, const uint8_t* arg, void* dH, int accumulate, long long G, int k,
                       int C, void* stream);
+/* DropPath of APFViTLayer (src/models/apf_utils.py:258,280,290; timm DropPath: x * Bernoulli(keep)/keep per sample) without an
+   elementwise pass: the branch's last GEMM runs with weights scaled by 1/keep and adds the residual for every sample, then
+   p4p_rows_restore_f32 puts dst[b] = src[b] back for the dropped samples (keep[b] == 0; keep is [B] u8); in the backward
+   p4p_rows_zero_bf16 clears the branch gradient rows of the same samples.  dst/src [B, per_sample] f32, x [B, per_sample] bf16. */
+int p4p_rows_restore_f32(float* dst, const float* src, const uint8_t* keep, int B, long long per_sample, void* stream);
+int p4p_rows_zero_bf16(void* x, const uint8_t* keep, int B, long long per_sample, void* stream);
+/* AdapterLayer bottleneck between its two GEMMs (src/models/apf_utils.py:222-226): down bf16 = dropout_p(relu(pre)) over n
+   elements; u (NULL when p == 0) holds uniform [0,1) draws, an element is kept where u >= p and scaled by 1/(1-p);
+   gate f32 = relu'(pre) * dropout factor.  bwd: dpre bf16 = ddown * gate. */
+int p4p_adapter_mid_fwd(const float* pre, const float* u, float p, void* down_bf16, float* gate, long long n, void* stream);
+int p4p_adapter_mid_bwd(const float* ddown, const float* gate, void* dpre_bf16, long long n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,79 @@
+"""CPU: the APF drop-in's module tree, state-dict names and freeze rule equal the oracle's (= the reference's), the
+scheduler restatement, the FLOP model of bench.py, and no silent CPU compute."""
+import pytest
+import torch
+
+import p4p_amd
+from p4p_amd import apf as PA
+from p4p_amd.apf_trainer import CosineWarmupLR
+from oracle import apf_oracle as A
+
+
+def _pair(**kw):
+    cfg = dict(num_classes=15, embedding_dim=192, npoint=64, nsample=32, depth=2, num_heads=3)
+    cfg.update(kw)
+    return A.AdaptPointFormer(**cfg), PA.AdaptPointFormer(vit_name=None, pretrained=False, **cfg)
+
+
+def test_state_dict_names_shapes_and_freeze_match_reference_layout():
+    o, m = _pair()
+    so, sm = o.state_dict(), m.state_dict()
+    assert list(so.keys()) == list(sm.keys())
+    assert all(so[k].shape == sm[k].shape for k in so)
+    assert m.load_state_dict(A.seeded_state_dict(o, seed=1), strict=True)
+    want = {n for n, p in o.named_parameters() if p.requires_grad}
+    assert {n for n, p in m.named_parameters() if p.requires_grad} == want
+    assert {n.split('.')[0] for n in want} == {'head', 'encoder_norm', 'point_encoder'}      # apf.py:335-346
+    # keys a reference checkpoint carries (apf.py module tree)
+    for k in ('point_encoder.encoder.first_conv.0.weight', 'point_encoder.encoder.second_conv.3.bias',
+              'blocks.0.attention.qkv.weight', 'blocks.1.adapter.adapter_norm.weight', 'blocks.1.adapter.scale',
+              'blocks.0.mlp.fc1.weight', 'encoder_norm.weight', 'head.mlp_head.8.weight'):
+        assert k in sm
+    assert sm['point_encoder.encoder.first_conv.0.weight'].shape == (256, 6, 1)
+    assert float(_pair()[1].blocks[0].adapter.up_proj.weight.abs().max()) == 0.0            # apf_utils.py:193
+
+
+def test_reference_default_shapes():
+    m = PA.AdaptPointFormer(vit_name='vit_base_patch16_224', pretrained=False)
+    assert len(m.blocks) == 12 and m.blocks[0].attention.num_heads == 12
+    assert m.point_encoder.group.num_group == 196 and m.point_encoder.group.group_size == 32
+    n_train = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    n_all = sum(p.numel() for p in m.parameters())
+    assert 4.5e6 < n_train < 5.0e6 and 9.0e7 < n_all < 9.2e7
+    # drop-path rates rise linearly to dropout_path_rate (apf.py:298); block 0 has none
+    assert isinstance(m.blocks[0].drop_path, torch.nn.Identity)
+    assert m.blocks[11].drop_path.drop_prob == pytest.approx(0.1)
+    with pytest.raises(RuntimeError, match='P4P_PRETRAINED_DIR'):
+        PA.AdaptPointFormer()                                                               # pretrained=True never downloads
+
+
+def test_cpu_tensors_are_rejected_not_silently_computed():
+    _, m = _pair()
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m(torch.zeros(2, 128, 3))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        PA.MortonEncoder.points_to_morton(torch.zeros(2, 16, 3))
+    with pytest.raises(NotImplementedError):
+        PA.Encoder(768, 8)
+
+
+def test_cosine_warmup_schedule():
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=5e-4)
+    s = CosineWarmupLR(opt, t_initial=100, warmup_t=10, warmup_lr_init=1e-3)
+    lr = lambda: opt.param_groups[0]['lr']
+    assert lr() == pytest.approx(1e-3)
+    s.step(5)
+    assert lr() == pytest.approx(7.5e-4)
+    s.step(10)
+    assert lr() == pytest.approx(0.5 * 5e-4 * (1 + torch.cos(torch.tensor(torch.pi * 0.1)).item()))
+    s.step(100)
+    assert lr() == 0.0
+
+
+def test_bench_flop_model():
+    import bench
+    # ~8.13 MFLOP per position x 196*32 positions ~ 51 GF forward per cloud
+    enc_fwd = 196 * 32 * 2.0 * (6 * 256 + 256 * 512 + 512 * 768 + 1536 * 1536 + 1536 * 768)
+    assert 50.5e9 < enc_fwd < 51.5e9
+    assert bench.apf_flop_per_cloud() == pytest.approx(3 * enc_fwd + 2 * 12 * (24 * 196 * 768 ** 2 + 4 * 196 ** 2 * 768
+                                                                               + 4 * 196 * 768 * 64))

@@ -57,3 +57,33 @@ def test_trainer_rejects_cpu_device(tmp_path):
     mc, dc, tc = _configs(tmp_path)
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         p4p_amd.Pix4PointTrainer(mc, dc, tc, device='cpu', output_dir=str(tmp_path / 'x'))
+
+
+def test_apf_trainer_end_to_end(tmp_path):
+    """reference src/train/apf_trainer.py: CSV header with the learning-rate column, model_best.pt, the checkpoint dict,
+    frozen blocks untouched by training, trainable tokenizer / head moving."""
+    mc = {'num_classes': 8, 'in_channels': 3, 'vit_name': 'vit_custom_d192_l2_h3', 'pretrained': False,
+          'embedding_dim': 192, 'npoint': 32, 'nsample': 16, 'dropout_rate': 0.1, 'drop_path_rate': 0.1, 'depth': 2,
+          'num_heads': 3}
+    dc = {'root_dir': 'synthetic', 'variant': 'main_split', 'augmentation': 'none', 'train_num_points': 256,
+          'test_num_points': 128, 'num_samples': 64}
+    tc = {'batch_size': 16, 'epochs': 3, 'save_interval': 1, 'label_smoothing': 0.3, 'learning_rate': 2e-3,
+          'weight_decay': 5e-2, 'warmup_epochs': 1, 'warmup_lr_init': 1e-3}
+    out = str(tmp_path / 'apf')
+    torch.manual_seed(0)
+    tr = p4p_amd.APFTrainer(mc, dc, tc, device='cuda', output_dir=out)
+    frozen0 = tr.model.blocks[1].mlp.fc1.weight.detach().clone()
+    enc0 = tr.model.point_encoder.encoder.second_conv[3].weight.detach().clone()
+    tr.train()
+    rows = list(csv.reader(open(os.path.join(out, 'training_metrics.csv'))))
+    assert rows[0] == ['epoch', 'train_loss', 'train_accuracy', 'test_loss', 'test_accuracy', 'learning_rate']
+    assert len(rows) == 1 + tc['epochs']
+    losses = [float(r[1]) for r in rows[1:]]
+    assert all(l == l and l < 10 for l in losses) and losses[-1] < losses[0], losses
+    assert [float(r[5]) for r in rows[1:]][0] == pytest.approx(1e-3)         # epoch 0 ran at warmup_lr_init
+    assert os.path.exists(os.path.join(out, 'model_best.pt'))
+    ck = torch.load(os.path.join(out, 'model_epoch_2.pt'), map_location='cpu', weights_only=False)
+    assert set(ck) == {'epoch', 'model_state_dict', 'optimizer_state_dict', 'accuracy', 'model_config', 'dataset_config'}
+    assert 'blocks.0.adapter.down_proj.weight' in ck['model_state_dict']
+    assert torch.equal(frozen0, tr.model.blocks[1].mlp.fc1.weight)
+    assert not torch.equal(enc0, tr.model.point_encoder.encoder.second_conv[3].weight)
