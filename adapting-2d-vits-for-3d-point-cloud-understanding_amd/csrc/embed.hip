@@ -247,6 +247,56 @@ __global__ void bn_relu_bf16_kernel(const __bf16* __restrict__ x, __bf16* __rest
     *reinterpret_cast<bvec*>(y + e) = o;
 }
 
+// Column-resident variants for C % 8 == 0 (every width on the path): a thread owns 8 fixed channels, keeps their BatchNorm
+// constants in registers and walks down the rows, so the streams are pure 16-byte loads / stores with no per-element
+// index division and no per-element constant loads.  grid = (C / 8 / tpr, row blocks); block = 256 threads =
+// (256 / tpr) rows x tpr column octets, tpr = gcd(C / 8, 256).
+#define BNC_ROWS 256
+static int bnc_tpr(int C) {            // gcd(C / 8, 256): a power of two
+    int t = C / 8, g = 1;
+    while (g < 256 && t % (2 * g) == 0) g *= 2;
+    return g;
+}
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_colwise_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y,
+                                                         const __bf16* __restrict__ H, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, const float* __restrict__ sums,
+                                                         float invNp, long long rows, int C, int tpr) {
+    const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr, rpp = 256 / tpr;
+    const int c = (blockIdx.x * tpr + tc) * 8;
+    float sc[8], sh[8], a[8], b[8];          // BWD: dH = sc*dy*mask - a - b*h  with a = sc*(m1 - mu*is*m2), b = sc*is*m2
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        sc[i] = scale[c + i];
+        sh[i] = shift[c + i];
+        if (BWD) {
+            const float m1 = sums[c + i] * invNp, m2 = sums[C + c + i] * invNp, mu = mean[c + i], is = invstd[c + i];
+            a[i] = sc[i] * (m1 - mu * is * m2);
+            b[i] = sc[i] * is * m2;
+        }
+    }
+    const long long r0 = (long long)blockIdx.y * BNC_ROWS, r1 = r0 + BNC_ROWS < rows ? r0 + BNC_ROWS : rows;
+    for (long long r = r0 + tr; r < r1; r += rpp) {
+        const size_t o = (size_t)r * C + c;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + o);
+        bf16x8 out;
+        if (BWD) {
+            const bf16x8 h = *reinterpret_cast<const bf16x8*>(H + o);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float hv = bf2f(h[i]);
+                const float dy = (sc[i] * hv + sh[i] > 0.f) ? bf2f(v[i]) : 0.f;
+                out[i] = f2bf(sc[i] * dy - a[i] - b[i] * hv);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) out[i] = f2bf(fmaxf(sc[i] * bf2f(v[i]) + sh[i], 0.f));
+        }
+        *reinterpret_cast<bf16x8*>(y + o) = out;
+    }
+}
+
 // tokens[g][c] = max_j relu(scale*H3[g*k+j][c] + shift); thread = (g, channel quad)
 __global__ void bn_relu_maxpool_kernel(const __bf16* __restrict__ H3, const float* __restrict__ scale,
                                        const float* __restrict__ shift, __bf16* __restrict__ tok_bf16,
@@ -641,10 +691,12 @@ extern "C" int p4p_bn_relu_bf16(const void* x, void* y, const float* scale, cons
                                 void* stream) {
     P4P_CHECK(x && y && scale && shift && rows >= 1 && C % 4 == 0, "p4p_bn_relu_bf16: bad arguments");
     long long n = rows * C;
-    if (C % 8 == 0)
-        hipLaunchKernelGGL(bn_relu_bf16_kernel<8>, dim3(ceil_div(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
-                           (const __bf16*)x, (__bf16*)y, scale, shift, n, C);
-    else
+    if (C % 8 == 0) {
+        const int tpr = bnc_tpr(C);
+        hipLaunchKernelGGL(bn_colwise_kernel<false>, dim3(C / 8 / tpr, ceil_div(rows, BNC_ROWS)), dim3(256), 0,
+                           (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, (const __bf16*)nullptr, scale, shift,
+                           (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.f, rows, C, tpr);
+    } else
         hipLaunchKernelGGL(bn_relu_bf16_kernel<4>, dim3(ceil_div(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
                            (const __bf16*)x, (__bf16*)y, scale, shift, n, C);
     P4P_LAUNCH_CHECK();
@@ -697,10 +749,12 @@ extern "C" int p4p_relu_bn_bwd(void* dY, const void* H, const float* scale, cons
     P4P_LAUNCH_CHECK();
     if (p4p_colreduce_f32(partial, sums, nb, (long long)2 * C, 2 * C, 0.f, stream)) return 2;
     long long n = rows * C;
-    if (C % 8 == 0)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<8>, dim3(ceil_div(n / 8, 256)), dim3(256), 0, st, (__bf16*)dY,
-                           (const __bf16*)H, scale, shift, mean, invstd, sums, (float)(1.0 / (double)rows), n, C);
-    else
+    if (C % 8 == 0) {
+        const int tpr = bnc_tpr(C);
+        hipLaunchKernelGGL(bn_colwise_kernel<true>, dim3(C / 8 / tpr, ceil_div(rows, BNC_ROWS)), dim3(256), 0, st,
+                           (const __bf16*)dY, (__bf16*)dY, (const __bf16*)H, scale, shift, mean, invstd, sums,
+                           (float)(1.0 / (double)rows), rows, C, tpr);
+    } else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ceil_div(n / 4, 256)), dim3(256), 0, st, (__bf16*)dY,
                            (const __bf16*)H, scale, shift, mean, invstd, sums, (float)(1.0 / (double)rows), n, C);
     P4P_LAUNCH_CHECK();
