@@ -144,7 +144,9 @@ class _ApfEncoderFn(torch.autograd.Function):
         dW4a = ops.gemm_wgrad(dU, fg)
         dfg = ops.gemm_tn(dU, W4aT, ops.EPI_BF16)
         ops.group_max_bwd(dfg, arg3, G, gs, into=df)                            # the pooled vector's share joins df
-        dW3, db3 = ops.gemm_wgrad(df, F2, want_bias=True)
+        # first_conv[6].bias moves f, its pooled copy and therefore H4 by one constant per channel, which the train-mode
+        # BatchNorm behind removes: its gradient (the column sums of df) is zero in exact arithmetic -- no pass is spent on it
+        dW3, db3 = ops.gemm_wgrad(df, F2), torch.zeros(E, dtype=torch.float32, device=dtok.device)
         dF2 = ops.gemm_tn(df, W3T, ops.EPI_BF16)
         del df
         s2 = ops.relu_bn_bwd_(dF2, H2, sc2, sh2, mean2, is2)

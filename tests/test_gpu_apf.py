@@ -170,8 +170,8 @@ def test_encoder_against_reference_fixture(golden_dir, tag):
     assert max(errs.values()) < 0.25 and sorted(errs.values())[len(errs) // 2] < 0.15, errs
     # first_conv[6].bias shifts f, its pooled copy and hence H4 by one constant per channel, which the BatchNorm behind
     # removes: its gradient is zero in exact arithmetic (the reference's value is fp32 noise)
-    scale = float(fc[6].weight.grad.abs().max())
-    assert float(fc[6].bias.grad.abs().max()) < 2e-2 * scale and float(g('g_conv6_b').abs().max()) < 2e-2 * scale
+    assert float(fc[6].bias.grad.abs().max()) == 0.0
+    assert float(g('g_conv6_b').abs().max()) < 1e-3 * float(fc[6].weight.grad.abs().max())
     for conv in (fc[0], fc[3], sc[0]):          # a bias in front of train-mode BatchNorm has zero gradient
         assert float(conv.bias.grad.abs().max()) == 0.0
     # first layer: fp32-class (hi/lo split operands); fourth layer: its input went through three bf16 GEMMs
@@ -203,11 +203,8 @@ def test_encoder_backward_vs_rounding_matched_statement(G, ec):
     assert rel_l2(tok.reshape(G, ec), te) < 6e-3
     errs = {}
     for n, p in m.named_parameters():
-        if n in ('first_conv.0.bias', 'first_conv.3.bias', 'second_conv.0.bias'):
-            assert float(p.grad.abs().max()) == 0.0            # exactly zero in exact arithmetic
-            continue
-        if n == 'first_conv.6.bias':                           # zero in exact arithmetic too (see the fixture test)
-            assert float(p.grad.abs().max()) < 2e-2 * float(m.first_conv[6].weight.grad.abs().max())
+        if n in ('first_conv.0.bias', 'first_conv.3.bias', 'second_conv.0.bias', 'first_conv.6.bias'):
+            assert float(p.grad.abs().max()) == 0.0            # exactly zero in exact arithmetic (see the fixture test)
             continue
         errs[n] = rel_l2(p.grad, params[n].grad)
     assert max(errs.values()) < 2e-2, errs
