@@ -278,6 +278,160 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
     }
 }
 
+// ---- QT query tiles per wave (workgroup = QT * 64 queries).  Every wave of the kernel above reads the whole K and V tile from
+// LDS for its 16 queries: 16 KiB per wave and tile against 16 MFMAs, i.e. the LDS pipe (64 KiB per workgroup-tile) is as busy
+// as the matrix pipe.  With QT tiles per wave every K / V fragment read feeds QT MFMAs: LDS bytes per FLOP drop by QT.
+template <bool MASK, int QT>
+__device__ __forceinline__ void attn_fwd_tile_q(const char* kt_lds, const char* vt_lds, const bf16x8 (&qf)[QT][2],
+                                                f32x4 (&o)[QT][4], float (&m)[QT], float (&lsum)[QT], float c, int key0, int T,
+                                                int lane) {
+    const int g = lane >> 4;
+    const int nvalid = MASK ? T - key0 : 64;
+    f32x4 s[QT][4];
+#pragma unroll
+    for (int k16 = 0; k16 < 4; ++k16) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) s[t][k16] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!MASK || k16 * 16 < nvalid) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 kf = frag_rows(kt_lds, k16, ks, lane);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) s[t][k16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], s[t][k16], 0, 0, 0);
+            }
+        }
+    }
+    bf16x8 pb[QT][2];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        if (MASK) {
+#pragma unroll
+            for (int k16 = 0; k16 < 4; ++k16)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (k16 * 16 + 4 * g + r >= nvalid) s[t][k16][r] = -INFINITY;
+        }
+        float mx = fmaxf(fmaxf(s[t][0][0], s[t][0][1]), fmaxf(s[t][0][2], s[t][0][3]));
+#pragma unroll
+        for (int k16 = 1; k16 < 4; ++k16)
+            mx = fmaxf(mx, fmaxf(fmaxf(s[t][k16][0], s[t][k16][1]), fmaxf(s[t][k16][2], s[t][k16][3])));
+        mx = xor_lanes_max(mx) * c;
+        const float mnew = fmaxf(m[t], mx);
+        const float alpha = __builtin_amdgcn_exp2f(m[t] - mnew);
+        m[t] = mnew;
+        float ps = 0.f;
+#pragma unroll
+        for (int k16 = 0; k16 < 4; ++k16)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[t][k16][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][k16][r], c, -mnew));
+                ps += s[t][k16][r];
+            }
+        lsum[t] = lsum[t] * alpha + ps;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[t][d] *= alpha;
+        pb[t][0] = pack_pair(s[t][0], s[t][1]);
+        pb[t][1] = pack_pair(s[t][2], s[t][3]);
+    }
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+        if (MASK && ss * 32 >= nvalid) continue;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const bf16x8 vf = frag_tr(vt_lds, ss, d, lane);
+#pragma unroll
+            for (int t = 0; t < QT; ++t) o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[t][ss], o[t][d], 0, 0, 0);
+        }
+    }
+}
+
+template <int QT>
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_q_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * TILE_BYTES];     // [buf][K|V]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
+    const int T = p.T, D = p.D;
+    // same XCD-aware decode as attn_block, with QT*64-query blocks
+    const int nblk = (T + QT * 64 - 1) / (QT * 64);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bh = (slot / nblk) * 8 + xcd;
+    const int qb = slot - (slot / nblk) * nblk;
+    if (bh >= p.B * p.H) return;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const size_t ld = (size_t)3 * D;
+    const __bf16* seq = p.qkv + (size_t)b * T * ld;
+    const __bf16* kbase = seq + D + h * HD;
+    const __bf16* vbase = seq + 2 * D + h * HD;
+    const float c = p.scale * 1.4426950408889634f;
+
+    const int q0 = qb * QT * 64 + wave * QT * 16;            // this wave's QT consecutive 16-query tiles
+    bf16x8 qf[QT][2];
+    f32x4 o[QT][4];
+    float m[QT], lsum[QT];
+#pragma unroll
+    for (int tq = 0; tq < QT; ++tq) {
+        int q = q0 + tq * 16 + i;
+        q = q < T ? q : T - 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[tq][ks] = *reinterpret_cast<const bf16x8*>(seq + (size_t)q * ld + h * HD + ks * 32 + g * 8);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[tq][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m[tq] = -INFINITY;
+        lsum[tq] = 0.f;
+    }
+    const int rin = lane >> 3, chunk = (lane & 7) ^ rin;
+    const __bf16* ksrc[2];
+    const __bf16* vsrc[2];
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+        const size_t off = (size_t)((wave * 2 + qq) * 8 + rin) * ld + chunk * 8;
+        ksrc[qq] = kbase + off;
+        vsrc[qq] = vbase + off;
+    }
+    const size_t tile_step = (size_t)64 * ld;
+    auto stage_any = [&](int kt, char* buf) {
+        if ((kt + 1) * 64 <= T) {
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                __builtin_amdgcn_global_load_lds(GLB_PTR(ksrc[qq] + kt * tile_step), LDS_PTR(buf + (wave * 2 + qq) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_PTR(vsrc[qq] + kt * tile_step), LDS_PTR(buf + TILE_BYTES + (wave * 2 + qq) * 1024), 16, 0, 0);
+            }
+        } else {
+            stage_rows(kbase, ld, kt * 64, T, buf, wave, lane);
+            stage_rows(vbase, ld, kt * 64, T, buf + TILE_BYTES, wave, lane);
+        }
+    };
+    const int nkt = (T + 63) / 64, nfull = T / 64;
+    stage_any(0, lds);
+    const bool wave_active = q0 < T;
+    for (int kt = 0; kt < nfull; ++kt) {
+        STAGE_FENCE();
+        const char* cur = lds + (kt & 1) * 2 * TILE_BYTES;
+        if (kt + 1 < nkt) stage_any(kt + 1, lds + ((kt + 1) & 1) * 2 * TILE_BYTES);
+        if (wave_active) attn_fwd_tile_q<false, QT>(cur, cur + TILE_BYTES, qf, o, m, lsum, c, kt * 64, T, lane);
+    }
+    if (nfull < nkt) {
+        STAGE_FENCE();
+        const char* cur = lds + (nfull & 1) * 2 * TILE_BYTES;
+        if (wave_active) attn_fwd_tile_q<true, QT>(cur, cur + TILE_BYTES, qf, o, m, lsum, c, nfull * 64, T, lane);
+    }
+#pragma unroll
+    for (int tq = 0; tq < QT; ++tq) {
+        const float l = xor_lanes_sum(lsum[tq]);
+        const float inv = 1.0f / l;
+        const int q = q0 + tq * 16 + i;
+        if (q < T) {
+            __bf16* dst = p.out + ((size_t)b * T + q) * D + h * HD;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                bf16x4 w = {f2bf(o[tq][d][0] * inv), f2bf(o[tq][d][1] * inv), f2bf(o[tq][d][2] * inv), f2bf(o[tq][d][3] * inv)};
+                *reinterpret_cast<bf16x4*>(dst + d * 16 + 4 * g) = w;
+            }
+            if (g == 0 && p.lse2) p.lse2[((size_t)b * p.H + h) * T + q] = m[tq] + __builtin_amdgcn_logf(l);
+        }
+    }
+}
+
 // Forward for short sequences (T <= RES_ROWS): one workgroup = one (b,h), all of K and V resident in LDS (2 x 34 KiB),
 // 8 waves that each take whole 16-query tiles (17 at T = 257) and run over the key tiles with NO further barrier or
 // staging wait.  The streaming kernel above spends its time on per-workgroup fixed latencies and one barrier + LDS-DMA
@@ -772,8 +926,19 @@ extern "C" int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B,
     static const bool no_res = getenv("P4P_ATTN_NO_RES") != nullptr;          // A/B switch (tools/ab_bench.sh)
     if (T <= RES_ROWS - 31 && T >= 64 && !no_res)
         hipLaunchKernelGGL(attn_fwd_res_kernel, dim3(B * H), dim3(RES_NW * 64), 0, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(attn_fwd_kernel, attn_grid(B, T, H), dim3(ATT_THREADS), 0, (hipStream_t)stream, p);
+    else {
+        // measured at B=256, H=12 (tools/attn_ab.py): T=513: 542 / 499 / 533 us for 1 / 2 / 4 tiles per wave; T=2049: 5398 / 4643 / 4501
+        static const int env_qt = getenv("P4P_ATTN_FWD_QT") ? atoi(getenv("P4P_ATTN_FWD_QT")) : 0;   // A/B switch
+        const int qt = env_qt ? env_qt : (T >= 1024 ? 4 : 2);
+        if (qt == 2 && T > 128)
+            hipLaunchKernelGGL(attn_fwd_q_kernel<2>, dim3((unsigned)(ceil_div((long long)B * H, 8) * 8 * ceil_div(T, 128))),
+                               dim3(ATT_THREADS), 0, (hipStream_t)stream, p);
+        else if (qt == 4 && T > 256)
+            hipLaunchKernelGGL(attn_fwd_q_kernel<4>, dim3((unsigned)(ceil_div((long long)B * H, 8) * 8 * ceil_div(T, 256))),
+                               dim3(ATT_THREADS), 0, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL(attn_fwd_kernel, attn_grid(B, T, H), dim3(ATT_THREADS), 0, (hipStream_t)stream, p);
+    }
     P4P_LAUNCH_CHECK();
     return 0;
 }
