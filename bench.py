@@ -190,6 +190,47 @@ def instrumented_roofline(stepper, batch, steps):
     }
 
 
+def index_ops_roofline(B, N, S, k, device, iters=20):
+    """FPS and kNN on their own (SURVEY.md section 8d asks for both figures per op): `hbm` = compulsory bytes
+    ((12N+8S) B for FPS, (12N+12S+4Sk) B for kNN) / time against 8 TB/s -- tiny BY CONSTRUCTION: both kernels read the
+    cloud from HBM exactly once and then work on chip; `onchip` = the operand traffic the algorithm implies (FPS: S rounds x
+    16 B per point; kNN: S x N pair distances x 12 B) / time against the aggregate LDS rate 256 CUs x 128 B/clk x 2.4 GHz
+    = 78.6 TB/s -- the figure that says how busy the on-chip side is (FPS keeps the points in registers, so its real
+    bound is the latency of S dependent arg-max rounds)."""
+    from p4p_amd import ops
+    g = torch.Generator().manual_seed(5)
+    pts = (torch.rand(B, N, 3, generator=g) * 2 - 1).to(device)
+    start = torch.zeros(B, dtype=torch.long, device=device)
+
+    def timeit(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / iters
+    t_fps = timeit(lambda: ops.fps(pts, S, start))
+    idx = ops.fps(pts, S, start)
+    cen = torch.gather(pts, 1, idx.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    t_knn = timeit(lambda: ops.knn(pts, cen, k))
+    lds_peak = 256 * 128 * 2.4e9
+    fps_hbm, knn_hbm = (12 * N + 8 * S) * B, (12 * N + 12 * S + 4 * S * k) * B
+    fps_on, knn_on = S * 16 * N * B, S * N * 12 * B
+    return {
+        'shape': {'B': B, 'N': N, 'S': S, 'k': k},
+        'fps': {'us': t_fps * 1e6, 'hbm_GBps': fps_hbm / t_fps * 1e-9, 'hbm_frac': fps_hbm / t_fps / 8e12,
+                'onchip_TBps': fps_on / t_fps * 1e-12, 'onchip_frac': fps_on / t_fps / lds_peak,
+                'bound': 'latency of S dependent arg-max rounds (%.2f us per round)' % (t_fps * 1e6 / S)},
+        'knn': {'us': t_knn * 1e6, 'hbm_GBps': knn_hbm / t_knn * 1e-9, 'hbm_frac': knn_hbm / t_knn / 8e12,
+                'onchip_TBps': knn_on / t_knn * 1e-12, 'onchip_frac': knn_on / t_knn / lds_peak,
+                'pair_distance_TFLOPs': 8.0 * S * N * B / t_knn * 1e-12, 'bound': 'VALU / LDS (selection), not HBM'},
+    }
+
+
 def cpu_baseline(args, budget_s=25.0):
     """The CPU oracle (pure-torch fp32 restatement of the reference path) doing the same training step on the
     host cores, on a bounded sample: batch 8 of the same synthetic clouds, as many steps as fit the budget."""
@@ -326,6 +367,10 @@ def main():
     roof = None
     if rank == 0 and not args.no_roofline:
         roof = instrumented_roofline(stepper, batch, max(2, min(args.steps, 5)))
+        if apf:
+            roof['index_ops'] = index_ops_roofline(args.batch, args.points, 196, 32, device)
+        else:
+            roof['index_ops'] = index_ops_roofline(args.batch, args.points, args.points // 4, 16, device)
         log('instrumented roofline pass done')
     if distributed:
         dist.barrier()
