@@ -124,7 +124,8 @@ def test_free_functions_keep_reference_contract():
 
 
 # --------------------------------------------------------------------------------------------- encoder / linear
-@pytest.mark.parametrize('B,T,D,L,H', [(2, 65, 192, 2, 3), (2, 130, 768, 1, 12), (3, 257, 384, 2, 6)])
+@pytest.mark.parametrize('B,T,D,L,H', [(2, 65, 192, 2, 3), (2, 130, 768, 1, 12), (3, 257, 384, 2, 6),
+                                       (2, 513, 1024, 1, 16)])       # ViT-L width, streaming attention (N=2048 tokens)
 def test_encoder_forward_backward_vs_fp32_torch(B, T, D, L, H):
     torch.manual_seed(D + T)
     blocks = torch.nn.ModuleList([O.Block(D, H) for _ in range(L)])
@@ -194,7 +195,8 @@ def test_full_tiny_eval_logits_vs_golden_restatement(golden_dir):
     assert torch.equal(logits.argmax(1).cpu(), want.argmax(1))
 
 
-@pytest.mark.parametrize('D,L,H,B,N', [(192, 2, 3, 8, 1024), (768, 1, 12, 2, 256), (384, 3, 6, 3, 512), (768, 12, 12, 2, 1024)])
+@pytest.mark.parametrize('D,L,H,B,N', [(192, 2, 3, 8, 1024), (768, 1, 12, 2, 256), (384, 3, 6, 3, 512), (768, 12, 12, 2, 1024),
+                                       (1024, 1, 16, 2, 2048), (768, 1, 12, 1, 8192)])      # BASELINE configs 3 / 5 shapes
 def test_eval_logits_vs_oracle(D, L, H, B, N):
     oracle, model = build_pair(40, D, L, H, seed=D + L)
     oracle.eval(), model.eval()
