@@ -14,6 +14,7 @@ import os
 import torch
 import torch.nn as nn
 
+from . import augment as GA
 from .apf import AdaptPointFormer
 from .ddp import GradReducer, broadcast_parameters
 from .optim import FusedAdamW
@@ -70,6 +71,17 @@ class APFTrainer(Pix4PointTrainer):
         k = self.model_config['num_classes']
         self.train_dataset = SyntheticClouds(n, c['train_num_points'], k, seed=1234)
         self.test_dataset = SyntheticClouds(max(n // 4, 1), c['test_num_points'], k, seed=4321)
+        # the reference's per-cloud numpy transforms (:88-98: scale_point_cloud, center_and_normalize_point_cloud,
+        # rotate_point_cloud for training; center_and_normalize_point_cloud for testing) on the device batch
+        gen = [None]
+
+        def train_aug(points):
+            if gen[0] is None:
+                gen[0] = torch.Generator(device=points.device).manual_seed(1234 + self.rank)
+            points = GA.scale_point_cloud(points, generator=gen[0])
+            return GA.rotate_point_cloud(GA.normalize_point_cloud(points), generator=gen[0])
+        self.train_augment = train_aug
+        self.test_augment = GA.normalize_point_cloud
 
     # ---- reference :164-183
     def _init_optimizer(self) -> None:

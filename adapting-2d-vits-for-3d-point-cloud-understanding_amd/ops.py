@@ -525,3 +525,32 @@ def adapter_mid_bwd(ddown, gate):
     dpre = torch.empty(ddown.shape, dtype=torch.bfloat16, device=ddown.device)
     L.call('p4p_adapter_mid_bwd', L.ptr(ddown), L.ptr(gate), L.ptr(dpre), L.i64(ddown.numel()), _stream())
     return dpre
+
+
+# ---------------------------------------------------------------- batched augmentation
+AUG_NORMALIZE, AUG_AFFINE, AUG_JITTER, AUG_REPLACE, AUG_DROPOUT = 1, 2, 4, 8, 16
+
+
+def augment(points, flags, affine=None, jitter=None, clip=0.05, replace_mask=None, replace_u=None, replace_g=None,
+            dropout_mask=None, out=None):
+    """The reference's per-cloud augmentation chain (src/data/augment.py) for a batch, every random draw an input; see
+    include/p4p_hip.h: p4p_augment_f32."""
+    _chk(points, 'points', torch.float32, 3)
+    B, N, C = points.shape
+    if C != 3:
+        raise RuntimeError(f'augment: expected (B,N,3) clouds, got {tuple(points.shape)}')
+    _chk(flags, 'flags', torch.int32, 1)
+    for t, nm, dt, shp in ((affine, 'affine', torch.float32, (B, 12)), (jitter, 'jitter', torch.float32, (B, N, 3)),
+                           (replace_mask, 'replace_mask', torch.bool, (B, N)), (replace_u, 'replace_u', torch.float32, (B, N, 3)),
+                           (replace_g, 'replace_g', torch.float32, (B, N, 3)), (dropout_mask, 'dropout_mask', torch.bool, (B, N))):
+        if t is not None:
+            _chk(t, nm, dt)
+            if tuple(t.shape) != shp:
+                raise RuntimeError(f'augment: {nm} must have shape {shp}, got {tuple(t.shape)}')
+    if flags.shape[0] != B:
+        raise RuntimeError('augment: flags must have shape (B,)')
+    if out is None:
+        out = torch.empty_like(points)
+    L.call('p4p_augment_f32', L.ptr(points), L.ptr(out), L.ptr(flags), L.ptr(affine), L.ptr(jitter), float(clip),
+           L.ptr(replace_mask), L.ptr(replace_u), L.ptr(replace_g), L.ptr(dropout_mask), B, N, _stream())
+    return out

@@ -15,6 +15,7 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.optim as optim
 
+from .augment import TrainAugment
 from .ddp import broadcast_parameters, build_reducer
 from .optim import FusedAdamW
 from .pix4point import Pix4Point
@@ -92,6 +93,13 @@ class Pix4PointTrainer:
             raise NotImplementedError("ScanObjectNN loading is a later-round item (SURVEY.md section 8f-3)")
         assert self.train_dataset.num_classes == self.model_config['num_classes'], \
             "Number of classes in model config must match dataset classes"
+        # the reference normalises / augments one cloud at a time in numpy inside ScanObjectNN.__getitem__
+        # (src/data/scanobjectnn.py:186-205); here the batch is augmented on the GPU in one launch (augment.py)
+        self.train_augment = TrainAugment(normalize=c.get('normalize', False),
+                                          use_custom_augmentation=c.get('use_custom_augmentation', False),
+                                          augmentation_probability=c.get('augmentation_probability', 0.2),
+                                          seed=1234 + self.rank)
+        self.test_augment = TrainAugment(normalize=c.get('normalize', False), use_custom_augmentation=False)
 
     # ---- reference :85-98 (+ rank sharding)
     def _init_loaders(self) -> None:
@@ -189,6 +197,7 @@ class Pix4PointTrainer:
         for points, labels in self.train_loader:
             points = points.to(self.device, non_blocking=True)
             labels = labels.to(self.device, non_blocking=True)
+            points = self.train_augment(points)
             loss, logits = self.train_step(points, labels)
             loss_sum += loss.detach()
             correct += (logits.detach().argmax(1) == labels).sum()
@@ -207,7 +216,7 @@ class Pix4PointTrainer:
             for points, labels in self.test_loader:
                 points = points.to(self.device, non_blocking=True)
                 labels = labels.to(self.device, non_blocking=True)
-                logits = self.model(points)
+                logits = self.model(self.test_augment(points))
                 loss_sum += self.criterion(logits, labels)
                 correct += (logits.argmax(1) == labels).sum()
                 total += labels.size(0)

@@ -217,6 +217,18 @@ int p4p_rows_zero_bf16(void* x, const uint8_t* keep, int B, long long per_sample
 int p4p_adapter_mid_fwd(const float* pre, const float* u, float p, void* down_bf16, float* gate, long long n, void* stream);
 int p4p_adapter_mid_bwd(const float* ddown, const float* gate, void* dpre_bf16, long long n, void* stream);
 
+/* ---- batched augmentation: the per-cloud numpy chain of src/data/scanobjectnn.py:186-205 /
+   src/data/augment.py:4-191 for a whole batch resident in HBM, one workgroup per cloud.  Every random draw is an input.
+   flags [B] i32 per cloud: 1 normalize_point_cloud (:4-18), 2 affine p = p W + t (rotations :76-108,158-191,261-307, scalings
+   :35-47,193-226, shift :49-60 composed by the caller; affine [B][12] = W row-major then t), 4 jitter p += clip(jitter, +-clip)
+   (:62-74; jitter [B,N,3] = sigma * randn), 8 drop_and_replace_with_noise (:110-156; replace_mask [B,N] u8, replace_u uniform
+   [0,1) and replace_g = noise_std * randn, both [B,N,3]; the box is the cloud's CURRENT bounding box), 16 random_point_dropout
+   (:20-33; dropout_mask [B,N] u8: those points become point 0).  Steps run in that order; a step whose tensors are NULL is
+   skipped whatever the flag says.  points, out [B,N,3] f32 (may alias), N <= 12288. */
+int p4p_augment_f32(const float* points, float* out, const int32_t* flags, const float* affine, const float* jitter, float clip,
+                    const uint8_t* replace_mask, const float* replace_u, const float* replace_g, const uint8_t* dropout_mask,
+                    int B, int N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
