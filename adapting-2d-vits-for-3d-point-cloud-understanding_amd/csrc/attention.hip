@@ -627,6 +627,127 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_kernel(AttnParams 
     }
 }
 
+// ---- QT query tiles per wave (see attn_fwd_q_kernel): every K / V fragment read from LDS feeds QT MFMAs.
+template <bool RAGGED, int QT>
+__device__ __forceinline__ void attn_dq_tile_q(const char* kt_lds, const char* vt_lds, const bf16x8 (&qf)[QT][2],
+                                               const bf16x8 (&dof)[QT][2], f32x4 (&dq)[QT][4], float c, const float (&lse)[QT],
+                                               const float (&dl)[QT], int nvalid, int lane) {
+    const int g = lane >> 4;
+    f32x4 s[QT][4], dp[QT][4];
+#pragma unroll
+    for (int k16 = 0; k16 < 4; ++k16) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) s[t][k16] = dp[t][k16] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!RAGGED || k16 * 16 < nvalid) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 kf = frag_rows(kt_lds, k16, ks, lane), vf = frag_rows(vt_lds, k16, ks, lane);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    s[t][k16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][ks], s[t][k16], 0, 0, 0);
+                    dp[t][k16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[t][ks], dp[t][k16], 0, 0, 0);
+                }
+            }
+        }
+    }
+    bf16x8 db[QT][2];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+#pragma unroll
+        for (int k16 = 0; k16 < 4; ++k16)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][k16][r], c, -lse[t]));
+                if (RAGGED && k16 * 16 + 4 * g + r >= nvalid) pr = 0.f;
+                s[t][k16][r] = pr * (dp[t][k16][r] - dl[t]);
+            }
+        db[t][0] = pack_pair(s[t][0], s[t][1]);
+        db[t][1] = pack_pair(s[t][2], s[t][3]);
+    }
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+        if (RAGGED && ss * 32 >= nvalid) continue;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const bf16x8 kt = frag_tr(kt_lds, ss, d, lane);
+#pragma unroll
+            for (int t = 0; t < QT; ++t) dq[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, db[t][ss], dq[t][d], 0, 0, 0);
+        }
+    }
+}
+
+template <int QT>
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_q_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * 2 * TILE_BYTES];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
+    const int T = p.T, D = p.D;
+    const int nblk = (T + QT * 64 - 1) / (QT * 64);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int bh = (slot / nblk) * 8 + xcd;
+    const int qb = slot - (slot / nblk) * nblk;
+    if (bh >= p.B * p.H) return;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const size_t ld = (size_t)3 * D;
+    const __bf16* seq = p.qkv + (size_t)b * T * ld;
+    const __bf16* kbase = seq + D + h * HD;
+    const __bf16* vbase = seq + 2 * D + h * HD;
+    const float c = p.scale * 1.4426950408889634f;
+
+    const int q0 = qb * QT * 64 + wave * QT * 16;
+    bf16x8 qf[QT][2], dof[QT][2];
+    float lse[QT], dl[QT];
+    f32x4 dq[QT][4];
+#pragma unroll
+    for (int tq = 0; tq < QT; ++tq) {
+        int q = q0 + tq * 16 + i;
+        q = q < T ? q : T - 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[tq][ks] = *reinterpret_cast<const bf16x8*>(seq + (size_t)q * ld + h * HD + ks * 32 + g * 8);
+            dof[tq][ks] = *reinterpret_cast<const bf16x8*>(p.dout + ((size_t)b * T + q) * D + h * HD + ks * 32 + g * 8);
+        }
+        const size_t stat = ((size_t)b * p.H + h) * T + q;
+        lse[tq] = p.lse2[stat];
+        dl[tq] = p.delta[stat];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) dq[tq][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bool wave_active = q0 < T;
+    const int nkt = (T + 63) / 64, nfull = T / 64;
+    stage_rows(kbase, ld, 0, T, lds, wave, lane);
+    stage_rows(vbase, ld, 0, T, lds + TILE_BYTES, wave, lane);
+    for (int kt = 0; kt < nkt; ++kt) {
+        STAGE_FENCE();
+        const char* kt_lds = lds + (kt & 1) * 2 * TILE_BYTES;
+        const char* vt_lds = kt_lds + TILE_BYTES;
+        if (kt + 1 < nkt) {
+            char* nxt = lds + ((kt + 1) & 1) * 2 * TILE_BYTES;
+            stage_rows(kbase, ld, (kt + 1) * 64, T, nxt, wave, lane);
+            stage_rows(vbase, ld, (kt + 1) * 64, T, nxt + TILE_BYTES, wave, lane);
+        }
+        if (!wave_active) continue;
+        if (kt < nfull) attn_dq_tile_q<false, QT>(kt_lds, vt_lds, qf, dof, dq, c, lse, dl, 64, lane);
+        else attn_dq_tile_q<true, QT>(kt_lds, vt_lds, qf, dof, dq, c, lse, dl, T - kt * 64, lane);
+    }
+    const int tiles16 = ((T + 63) >> 6) * 4;                 // partial rows per sequence of the colsum buffer (one per 16-query tile)
+#pragma unroll
+    for (int tq = 0; tq < QT; ++tq) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) dq[tq][d] *= p.scale;
+        const int q = q0 + tq * 16 + i;
+        const int tile16 = (q0 >> 4) + tq;
+        if (p.colsum && tile16 < tiles16) wave_colsum(dq[tq], q < T, p.colsum + ((size_t)b * tiles16 + tile16) * ld + h * HD, lane);
+        if (q < T) {
+            __bf16* dst = p.out + ((size_t)b * T + q) * ld + h * HD;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                bf16x4 w = {f2bf(dq[tq][d][0]), f2bf(dq[tq][d][1]), f2bf(dq[tq][d][2]), f2bf(dq[tq][d][3])};
+                *reinterpret_cast<bf16x4*>(dst + d * 16 + 4 * g) = w;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // dK, dV: key on the lane, Q / dO tiles stream (each tile serves row reads AND transposed reads).
 //   S[q][key] = Q . K^T ; dP[q][key] = dO . V^T ; P = exp2(c S - lse2[q]) ; dS = P (dP - delta[q]) scale
@@ -974,7 +1095,12 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
     p.qkv = (const __bf16*)qkv; p.o = (const __bf16*)o; p.dout = (const __bf16*)dout; p.out = (__bf16*)dqkv;
     p.lse2 = (float*)lse2; p.delta = delta; p.colsum = colsum_partial; p.B = B; p.T = T; p.H = H; p.D = D; p.scale = scale;
     dim3 grid = attn_grid(B, T, H);
+    static const int env_dq_qt = getenv("P4P_ATTN_DQ_QT") ? atoi(getenv("P4P_ATTN_DQ_QT")) : 0;       // A/B switch (tools/attn_ab.py)
+    const int dq_qt = env_dq_qt ? env_dq_qt : 2;
     if (res) hipLaunchKernelGGL(attn_bwd_dq_res_kernel, dim3(B * H), dim3(RES_NW * 64), 0, st, p);
+    else if (dq_qt == 2 && T > 128)
+        hipLaunchKernelGGL(attn_bwd_dq_q_kernel<2>, dim3((unsigned)(ceil_div((long long)B * H, 8) * 8 * ceil_div(T, 128))),
+                           dim3(ATT_THREADS), 0, st, p);
     else hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(ATT_THREADS), 0, st, p);
     P4P_LAUNCH_CHECK();
     if (res && res_dkdv) {
