@@ -146,7 +146,7 @@ class ApfStepper:
         return loss
 
 
-def instrumented_roofline(stepper, batch, steps):
+def instrumented_roofline(stepper, batch, steps, measure=True):
     """Roofline of the dominant kernel, measured live: the library brackets exactly that kernel's launch with
     HIP events on the launch stream (include/p4p_hip.h: p4p_prof_enable / p4p_prof_collect) during `steps`
     extra training steps; algorithmic FLOPs = 2 M N K per launch.  Kind 1 = weight-gradient GEMM main kernel
@@ -156,14 +156,19 @@ def instrumented_roofline(stepper, batch, steps):
     lib = _lib.lib()
     res = {}
     for kind, name in ((1, 'gemm_wgrad3_kernel'), (2, 'gemm_tn (all tile configs / epilogues)')):
-        lib.p4p_prof_enable(kind)
-        for _ in range(steps):
+        if measure:
+            lib.p4p_prof_enable(kind)
+        for _ in range(steps):                      # EVERY rank takes these steps: they contain the gradient all-reduce
             stepper.step(*batch)
         torch.cuda.synchronize()
+        if not measure:
+            continue
         out = (ctypes.c_double * 3)()
         rc = lib.p4p_prof_collect(out)
         assert rc == 0
         res[kind] = {'name': name, 'ms': out[0], 'launches': out[1], 'flops': out[2]}
+    if not measure:
+        return None
     agg_fl = sum(r['flops'] for r in res.values())
     agg_ms = sum(r['ms'] for r in res.values())
     dom = max(res.values(), key=lambda r: r['ms'] if r['name'].startswith('gemm_wgrad3') else 0)
@@ -334,8 +339,16 @@ def main():
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        # rehearsal switches for a one-GPU box (tests/test_gpu_ddp.py style): P4P_DIST_BACKEND=gloo P4P_SINGLE_DEVICE=1 runs
+        # all ranks on device 0 with host-side collectives, to exercise the multi-rank control flow of this file
+        backend = os.environ.get('P4P_DIST_BACKEND', 'nccl')
+        if os.environ.get('P4P_SINGLE_DEVICE'):
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
 
@@ -365,8 +378,10 @@ def main():
     log(f'timed region: {args.steps} steps in {elapsed:.3f} s')
 
     roof = None
-    if rank == 0 and not args.no_roofline:
-        roof = instrumented_roofline(stepper, batch, max(2, min(args.steps, 5)))
+    if not args.no_roofline:
+        # all ranks run the instrumented steps (a step holds collectives); only rank 0 brackets its kernels with events
+        roof = instrumented_roofline(stepper, batch, max(2, min(args.steps, 5)), measure=rank == 0)
+    if rank == 0 and roof is not None:
         if apf:
             roof['index_ops'] = index_ops_roofline(args.batch, args.points, 196, 32, device)
         else:

@@ -92,3 +92,25 @@ def test_two_rank_data_parallel_step_on_one_gpu():
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == 'ok' for r in res), res
+
+
+def test_bench_two_rank_control_flow_on_one_gpu(tmp_path):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per process), rehearsed on ONE GPU with
+    host-side collectives (P4P_DIST_BACKEND=gloo, P4P_SINGLE_DEVICE=1): barriers, the max-over-ranks timing, the instrumented
+    roofline steps that every rank must take (they contain the gradient all-reduce) and exactly one JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, P4P_DIST_BACKEND='gloo', P4P_SINGLE_DEVICE='1', MASTER_ADDR='127.0.0.1')
+    for extra in ([], ['--workload', 'apf']):
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', str(_free_port()), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+               '--batch', '16', '--no-cpu-baseline'] + extra
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines = [l for l in res.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1, res.stdout
+        d = json.loads(lines[0])
+        assert d['n_gpus'] == 2 and d['steps'] == 2 and d['config']['global_batch'] == 32 and d['config']['parallelism'] == 'dp2'
+        assert d['value'] > 0 and 'roofline' in d and d['roofline']['achieved'] > 0
