@@ -251,6 +251,9 @@ def token_stream(x, weight, bias, cls_vec):
 _BLOCK_PARAMS = 12     # n1w n1b qkvw qkvb projw projb n2w n2b fc1w fc1b fc2w fc2b
 # bias gradients of qkv / fc1 from inside the kernels that produce dqkv / dh (A/B switches for tools/, default on)
 _FUSE_QKV_BIAS = os.environ.get('P4P_FUSE_QKV_BIAS', '1') != '0'   # -0.75 ms/step with the resident attention kernels (T <= 257)
+# above this T the column sums of dqkv take a separate pass.  A/B in one call: T=513 (N=2048, B=256) 114.6 -> 113.35 ms fused;
+# T=2049 (ViT-L, B=16) 119.65 vs 119.57: no difference, left on the separate pass
+_FUSE_QKV_BIAS_MAXT = int(os.environ.get('P4P_FUSE_QKV_BIAS_MAXT', '1024'))
 _FUSE_FC1_BIAS = os.environ.get('P4P_FUSE_FC1_BIAS', '1') != '0'
 # blk(x + pos) (src/models/pix4point.py:255): the fc2 epilogue of block l adds pos for block l+1 (A/B switch)
 _POS_IN_FC2 = os.environ.get('P4P_POS_IN_FC2', '1') != '0'
@@ -349,7 +352,7 @@ class _EncoderFn(torch.autograd.Function):
             datt = ops.gemm_tn(dxb, WprojT, ops.EPI_BF16)
             if wg:
                 dprojw, dprojb = ops.gemm_wgrad(dxb, att), dx_colsum
-            fuse_qkvb = _FUSE_QKV_BIAS and T <= 257        # pays only with the resident kernels (streaming ones are VALU-bound)
+            fuse_qkvb = _FUSE_QKV_BIAS and T <= _FUSE_QKV_BIAS_MAXT
             if wg and fuse_qkvb:
                 dqkv, dqkvb = ops.attention_bwd(qkv, att, datt, lse, B, T, H, want_colsum=True)
             else:
