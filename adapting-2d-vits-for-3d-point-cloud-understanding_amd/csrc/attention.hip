@@ -708,7 +708,17 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_q_kernel(AttnParam
         }
         const size_t stat = ((size_t)b * p.H + h) * T + q;
         lse[tq] = p.lse2[stat];
-        dl[tq] = p.delta[stat];
+        // delta[q] = dO[q] . O[q] over this head's 64 columns, from the dO fragment already in registers and the matching O
+        // fragment (no separate pass over O and dO); written out for the dK/dV kernel that follows on the stream
+        float part = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 of = *reinterpret_cast<const bf16x8*>(p.o + ((size_t)b * T + q) * D + h * HD + ks * 32 + g * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part += bf2f(dof[tq][ks][j]) * bf2f(of[j]);
+        }
+        dl[tq] = xor_lanes_sum(part);
+        if (g == 0 && q0 + tq * 16 + i < T) p.delta[stat] = dl[tq];
 #pragma unroll
         for (int d = 0; d < 4; ++d) dq[tq][d] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -1086,7 +1096,9 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
     hipStream_t st = (hipStream_t)stream;
     const bool res_dkdv = attn_resident_dkdv(T);
     const bool res = attn_resident(T) && (res_dkdv || !colsum_partial);
-    if (!res) {                                          // the resident dQ kernel computes delta itself
+    static const int env_dq_qt = getenv("P4P_ATTN_DQ_QT") ? atoi(getenv("P4P_ATTN_DQ_QT")) : 0;       // A/B switch (tools/attn_ab.py)
+    const bool dq_q = !res && (env_dq_qt ? env_dq_qt : 2) == 2 && T > 128;
+    if (!res && !dq_q) {                                 // the resident and the two-tile dQ kernels compute delta themselves
         hipLaunchKernelGGL(attn_delta_kernel, dim3(ceil_div((long long)B * T, 4)), dim3(256), 0, st, (const __bf16*)o,
                            (const __bf16*)dout, delta, B, T, H, D);
         P4P_LAUNCH_CHECK();
@@ -1095,10 +1107,8 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
     p.qkv = (const __bf16*)qkv; p.o = (const __bf16*)o; p.dout = (const __bf16*)dout; p.out = (__bf16*)dqkv;
     p.lse2 = (float*)lse2; p.delta = delta; p.colsum = colsum_partial; p.B = B; p.T = T; p.H = H; p.D = D; p.scale = scale;
     dim3 grid = attn_grid(B, T, H);
-    static const int env_dq_qt = getenv("P4P_ATTN_DQ_QT") ? atoi(getenv("P4P_ATTN_DQ_QT")) : 0;       // A/B switch (tools/attn_ab.py)
-    const int dq_qt = env_dq_qt ? env_dq_qt : 2;
     if (res) hipLaunchKernelGGL(attn_bwd_dq_res_kernel, dim3(B * H), dim3(RES_NW * 64), 0, st, p);
-    else if (dq_qt == 2 && T > 128)
+    else if (dq_q)
         hipLaunchKernelGGL(attn_bwd_dq_q_kernel<2>, dim3((unsigned)(ceil_div((long long)B * H, 8) * 8 * ceil_div(T, 128))),
                            dim3(ATT_THREADS), 0, st, p);
     else hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(ATT_THREADS), 0, st, p);
