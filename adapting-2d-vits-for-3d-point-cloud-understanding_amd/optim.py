@@ -107,4 +107,7 @@ class FusedAdamW(torch.optim.Optimizer):
             desc, ch, n = self._tables[(beta1, beta2, eps)][:3]
             L.call('p4p_adamw_step', L.ptr(desc), L.ptr(ch), n, L.ptr(coef), float(beta1), float(beta2), float(eps),
                    float(1.0 - beta1 ** step), float(1.0 - beta2 ** step), stream)
+        # the update kernel wrote the parameters through raw pointers: tell torch (autograd's in-place checks, and the
+        # bf16 operand caches of functional._bf16_weights, which are keyed on the version counter and MUST be re-made)
+        torch._C._increment_version([e[0] for e in entries])
         return total_norm if max_norm is not None else loss

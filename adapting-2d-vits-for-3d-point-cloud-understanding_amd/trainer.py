@@ -159,7 +159,7 @@ class Pix4PointTrainer:
     # ---- reference :135-151
     def train(self) -> None:
         best_acc = 0.0
-        for epoch in range(self.train_config['epochs']):
+        for epoch in range(getattr(self, 'start_epoch', 0), self.train_config['epochs']):      # > 0 after load_checkpoint
             if self.rank == 0:
                 print(f"\nEpoch {epoch+1}/{self.train_config['epochs']}")
             if self.distributed:
@@ -225,10 +225,15 @@ class Pix4PointTrainer:
 
     # ---- reference :199-217 (same dict keys)
     def _save_checkpoint(self, filename: str, epoch: int, accuracy: float) -> None:
-        torch.save({'epoch': epoch, 'model_state_dict': self.model.state_dict(),
-                    'optimizer_state_dict': self.optimizer.state_dict(), 'accuracy': accuracy,
-                    'model_config': self.model_config, 'dataset_config': self.dataset_config},
-                   os.path.join(self.output_dir, filename))
+        """The reference's six keys (what its load_checkpoint reads), plus what a true resume needs and the reference lacks
+        (SURVEY.md section 8f rank 4): scheduler state and the RNG streams."""
+        ck = {'epoch': epoch, 'model_state_dict': self.model.state_dict(),
+              'optimizer_state_dict': self.optimizer.state_dict(), 'accuracy': accuracy,
+              'model_config': self.model_config, 'dataset_config': self.dataset_config}
+        sched = getattr(self.scheduler, 'state_dict', None)
+        ck['resume'] = {'scheduler_state_dict': sched() if sched else None, 'torch_rng_state': torch.get_rng_state(),
+                        'cuda_rng_state': torch.cuda.get_rng_state(self.device)}
+        torch.save(ck, os.path.join(self.output_dir, filename))
 
     def load_checkpoint(self, checkpoint_path: str) -> None:
         checkpoint = torch.load(checkpoint_path, map_location=self.device, weights_only=False)
@@ -238,4 +243,11 @@ class Pix4PointTrainer:
         self.model.load_state_dict(checkpoint['model_state_dict'])
         self._init_optimizer()
         self.optimizer.load_state_dict(checkpoint['optimizer_state_dict'])
+        resume = checkpoint.get('resume')              # absent in checkpoints written by the reference
+        if resume:
+            if resume.get('scheduler_state_dict') is not None and hasattr(self.scheduler, 'load_state_dict'):
+                self.scheduler.load_state_dict(resume['scheduler_state_dict'])
+            torch.set_rng_state(resume['torch_rng_state'].cpu())
+            torch.cuda.set_rng_state(resume['cuda_rng_state'].cpu(), self.device)
+        self.start_epoch = checkpoint['epoch'] + 1
         print(f"Loaded checkpoint from epoch {checkpoint['epoch']} with accuracy {checkpoint['accuracy']:.4f}")

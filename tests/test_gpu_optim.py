@@ -76,3 +76,19 @@ def test_rejects_cpu_parameters():
     p.grad = torch.ones(4)
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         FusedAdamW([p]).step()
+
+
+def test_step_invalidates_the_bf16_operand_caches():
+    """The update kernel writes parameters through raw pointers; the GEMM operand copies cached on each weight are keyed on
+    the tensor's version counter, so the step must bump it -- otherwise every GEMM would keep running on the initial weights."""
+    from p4p_amd.functional import _bf16_weights
+    from p4p_amd.optim import FusedAdamW
+    w = torch.nn.Parameter(torch.randn(64, 64, device='cuda'))
+    wb0, _ = _bf16_weights(w, False)
+    assert _bf16_weights(w, False)[0] is wb0                       # cached while the weight is unchanged
+    v0 = w._version
+    w.grad = torch.ones_like(w)
+    FusedAdamW([w], lr=0.1).step()
+    assert w._version > v0
+    wb1, _ = _bf16_weights(w, False)
+    assert wb1 is not wb0 and torch.equal(wb1, w.detach().bfloat16()) and not torch.equal(wb1, wb0)
