@@ -108,5 +108,7 @@ def broadcast_parameters(model, src=0, process_group=None):
     """Same initial weights and buffers on every rank."""
     if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
         return
-    for t in list(model.parameters()) + list(model.buffers()):
+    ts = list(model.parameters()) + list(model.buffers())
+    for t in ts:
         dist.broadcast(t.data, src, group=process_group)
+    torch._C._increment_version(ts)        # `.data` writes do not bump the version the bf16 operand caches are keyed on
