@@ -298,8 +298,8 @@ class _ApfBlocksFn(torch.autograd.Function):
             dpre = ops.adapter_mid_bwd(ddown, dmask)
             _, WdT = _bf16_weights(dw, True)
             daln = ops.gemm_tn(dpre, WdT, ops.EPI_BF16)
-            ops.layernorm_bwd(dln2, x1, mean2, rstd2, n2w.detach(), dx=dx, dx_factor=2)     # r = ... + 2 x1
-            ops.layernorm_bwd(daln, x1, meanA, rstdA, anw.detach(), dx=dx, dx_bf16=dxb)
+            ops.layernorm_bwd(dln2, x1, mean2, rstd2, n2w.detach(), dx=dx, dx_factor=2, want_params=False)     # r = ... + 2 x1
+            ops.layernorm_bwd(daln, x1, meanA, rstdA, anw.detach(), dx=dx, dx_bf16=dxb, want_params=False)
             # ---- attention branch
             if keep_a is None:
                 _, WprojT = _bf16_weights(projw, True)
@@ -311,7 +311,7 @@ class _ApfBlocksFn(torch.autograd.Function):
             _, WqkvT = _bf16_weights(qkvw, True)
             dln1 = ops.gemm_tn(dqkv, WqkvT, ops.EPI_BF16)
             del dqkv, datt
-            ops.layernorm_bwd(dln1, xin, mean1, rstd1, n1w.detach(), dx=dx, dx_bf16=dxb)
+            ops.layernorm_bwd(dln1, xin, mean1, rstd1, n1w.detach(), dx=dx, dx_bf16=dxb, want_params=False)
         return (dx.view(B, T, D), None, None, None, None, None, dnw, dnb, *([None] * (L * _APF_BLOCK_PARAMS)))
 
 

@@ -169,7 +169,7 @@ def layernorm_fwd(x, gamma, beta, eps=1e-6, pos=None, want_sum=False, out_f32=Fa
 
 
 def layernorm_bwd(dy, xin, mean, rstd, gamma, dx=None, dgamma=None, dbeta=None, beta_acc=0.0, dx_bf16=None,
-                  dacc=None, dacc_init=False, want_dxsum=False, dx_factor=1):
+                  dacc=None, dacc_init=False, want_dxsum=False, dx_factor=1, want_params=True):
     """Returns (dx, dgamma, dbeta); if dx is given the LN gradient is ADDED to dx_factor * dx in place (dx_factor 1 or 2).
     dx_bf16 gets a bf16 copy of the result, dacc accumulates it (positional-embedding gradient)."""
     M, D = xin.shape
@@ -182,7 +182,9 @@ def layernorm_bwd(dy, xin, mean, rstd, gamma, dx=None, dgamma=None, dbeta=None, 
     if dx is None:
         dx = torch.empty(M, D, dtype=torch.float32, device=xin.device)
     dxsum = None
-    if dgamma is None:
+    if not want_params:                   # frozen LayerNorm (APF blocks): no parameter gradients, no reduce launch
+        dgamma = dbeta = None
+    elif dgamma is None:
         dgb = torch.empty(3, D, dtype=torch.float32, device=xin.device)     # contiguous: one reduce launch
         dgamma, dbeta, dxsum = dgb[0], dgb[1], dgb[2]
         beta_acc = 0.0
