@@ -29,6 +29,39 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
     }
 }
 
+// The same for R, C, ld multiples of 4 and 16-B aligned pointers: 64 x 64 tiles, float4 loads, 8-B bf16x4 stores both ways
+// (the per-step refresh of every weight's bf16 operand copies: 53 launches over 0.69 GB at ViT-B).
+__global__ __launch_bounds__(256) void cast_transpose4_kernel(const float* __restrict__ src, long long ld,
+                                                              __bf16* __restrict__ dst, __bf16* __restrict__ dstT,
+                                                              int R, int C) {
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // 16 column quads x 16 rows
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ty + j * 16, c = c0 + tx * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < R && c < C) v = *reinterpret_cast<const f32x4*>(src + (size_t)r * ld + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tile[ty + j * 16][tx * 4 + i] = v[i];
+        if (dst && r < R && c < C) {
+            const bf16x4 w = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            *reinterpret_cast<bf16x4*>(dst + (size_t)r * C + c) = w;
+        }
+    }
+    if (!dstT) return;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + ty + j * 16, r = r0 + tx * 4;
+        if (r < R && c < C) {
+            const bf16x4 w = {f2bf(tile[tx * 4][ty + j * 16]), f2bf(tile[tx * 4 + 1][ty + j * 16]),
+                              f2bf(tile[tx * 4 + 2][ty + j * 16]), f2bf(tile[tx * 4 + 3][ty + j * 16])};
+            *reinterpret_cast<bf16x4*>(dstT + (size_t)c * R + r) = w;
+        }
+    }
+}
+
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long long n) {
     long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (e + 3 < n) {
@@ -161,8 +194,14 @@ __global__ __launch_bounds__(256) void global_feat_bwd_kernel(float* __restrict_
 extern "C" int p4p_cast_transpose_f32_bf16(const float* src, long long ld_src, void* dst, void* dstT, int R, int C,
                                            void* stream) {
     P4P_CHECK(src && (dst || dstT) && R >= 1 && C >= 1 && ld_src >= C, "p4p_cast_transpose_f32_bf16: bad arguments");
-    hipLaunchKernelGGL(cast_transpose_kernel, dim3(ceil_div(C, 32), ceil_div(R, 32)), dim3(256), 0,
-                       (hipStream_t)stream, src, ld_src, (__bf16*)dst, (__bf16*)dstT, R, C);
+    const bool vec = R % 4 == 0 && C % 4 == 0 && ld_src % 4 == 0 && (reinterpret_cast<size_t>(src) & 15) == 0 &&
+                     (reinterpret_cast<size_t>(dst) & 7) == 0 && (reinterpret_cast<size_t>(dstT) & 7) == 0;
+    if (vec)
+        hipLaunchKernelGGL(cast_transpose4_kernel, dim3(ceil_div(C, 64), ceil_div(R, 64)), dim3(256), 0,
+                           (hipStream_t)stream, src, ld_src, (__bf16*)dst, (__bf16*)dstT, R, C);
+    else
+        hipLaunchKernelGGL(cast_transpose_kernel, dim3(ceil_div(C, 32), ceil_div(R, 32)), dim3(256), 0,
+                           (hipStream_t)stream, src, ld_src, (__bf16*)dst, (__bf16*)dstT, R, C);
     P4P_LAUNCH_CHECK();
     return 0;
 }

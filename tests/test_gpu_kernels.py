@@ -432,3 +432,16 @@ def test_pos_mlp0_matches_torch():
     (want * w).sum().backward()
     torch.testing.assert_close(lin_a.weight.grad, lin_b.weight.grad, rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(lin_a.bias.grad, lin_b.bias.grad, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize('R,C,col0,cols', [(768, 768, 0, None), (3072, 768, 0, None), (512, 512, 256, 256), (1536, 1536, 768, 768),
+                                            (256, 6, 0, None), (40, 256, 0, None), (130, 36, 4, 28), (64, 128, 2, 64)])
+def test_cast_weight_and_transpose_are_exact(R, C, col0, cols):
+    """fp32 master weight (or a column slice of it) -> bf16 W and W^T: exactly torch's round-to-nearest-even cast, on the
+    vectorised 64x64 path (sizes and offsets multiples of 4) and on the general 32x32 one."""
+    w = torch.randn(R, C, generator=torch.Generator().manual_seed(R + C)).to(DEV)
+    wb, wt = ops.cast_weight(w, True, True, cols=cols, col0=col0)
+    ref = w[:, col0:col0 + (cols if cols is not None else C - col0)].bfloat16()
+    assert torch.equal(wb, ref) and torch.equal(wt, ref.t().contiguous())
+    only_t = ops.cast_weight(w, False, True, cols=cols, col0=col0)[1]
+    assert torch.equal(only_t, ref.t().contiguous())
