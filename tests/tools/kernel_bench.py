@@ -7,7 +7,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import p4p_amd                      # noqa: E402
 from p4p_amd import ops             # noqa: E402
 from oracle import pix4point_oracle as O    # noqa: E402
