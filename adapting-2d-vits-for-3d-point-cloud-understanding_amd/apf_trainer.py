@@ -9,7 +9,6 @@ warm-up from ``warmup_lr_init`` over ``warmup_t`` epochs, then one cosine cycle 
 """
 import csv
 import math
-import os
 
 import torch
 import torch.nn as nn

@@ -12,7 +12,6 @@ checkpoints written by the reference's ``torch.optim.AdamW`` load into it and vi
 Difference from the two stock calls: the clipped gradients are consumed inside the update kernel and the ``.grad``
 tensors keep their unclipped values (nothing on the training path reads them after the step).
 """
-import math
 
 import torch
 

@@ -33,7 +33,6 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 
 # --------------------------------------------------------------------------------------------
