@@ -13,6 +13,12 @@ import torch
 
 from . import ops
 
+# tests set this to a dict to receive the tensors every stage of the next forward passes on (tokenizer activations, the two
+# token streams, per block: xin / ln1 / qkv / att / x1 / ln2 / g / xout, and the final LayerNorm output), so that a PyTorch
+# statement can be checked LINK BY LINK against the pipeline's own upstream tensors (tests/test_gpu_matched_parity.py)
+_CAPTURE = None
+
+
 def _bf16_weights(w, want_t, col0=0, cols=None):
     """bf16 operand copies (W, W^T) of an fp32 master weight.  The cache lives ON the parameter object
     (so it dies with it) and is invalidated by the tensor's version counter (any in-place update)."""
@@ -60,6 +66,8 @@ class _P3EmbedFn(torch.autograd.Function):
         sums3 = ops.colreduce(st3, st3.shape[0], 2 * C3) if training else None
         sc3, sh3, mean3, is3 = ops.bn_finalize(sums3, bn3, P, training)
         tok, arg3 = ops.bn_relu_maxpool(H3, sc3, sh3, G, k)
+        if _CAPTURE is not None:
+            _CAPTURE['embed'] = dict(F1=F1, pooled=pooled, U=U, H2=H2, F2=F2, H3=H3, tok=tok)
         if training:
             for bn in bns:
                 bn.num_batches_tracked += 1
@@ -301,7 +309,12 @@ class _EncoderFn(torch.autograd.Function):
                             resid2=pos2 if (_POS_IN_FC2 and l + 1 < L) else None)
             if train:
                 saved += [xin, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, hpre, g]
+            if _CAPTURE is not None:
+                _CAPTURE.setdefault('blocks', []).append(dict(xin=xin, ln1=ln1, qkv=qkv, att=att, x1=x1, ln2=ln2, g=g, xout=x,
+                                                              pos_added=bool(_POS_IN_FC2 and l + 1 < L)))
         y, _, meanN, rstdN = ops.layernorm_fwd(x, norm_w.detach(), norm_b.detach(), eps, out_f32=True, want_stats=train)
+        if _CAPTURE is not None:
+            _CAPTURE['encoder_out'] = y
         if train:
             ctx.save_for_backward(x, meanN, rstdN, norm_w, *bp, *saved)
         ctx.meta = (B, T, D, H, L, eps)

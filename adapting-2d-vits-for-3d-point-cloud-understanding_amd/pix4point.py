@@ -125,6 +125,8 @@ class PointViT(nn.Module):
             pe = F.linear(h, self.pos_embed[2].weight, self.pos_embed[2].bias)
             pos = torch.cat([self.cls_pos.expand(B, -1, -1), pe], dim=1)
             feats = torch.cat([self.cls_token.expand(B, -1, -1), xt], dim=1)
+        if F._CAPTURE is not None:
+            F._CAPTURE['streams'] = dict(centers=centers, tok=tok, h=h, pos=pos, feats=feats)
         feats = F.encoder(feats, pos, list(self.vit_blocks), self.norm, self.vit.num_heads, self.grad_sink)
         return p_list, x_list, feats
 

@@ -5,8 +5,13 @@ to ~1%) from the hard-gating flips that any bf16 activation storage causes again
 import torch
 
 
+ROUND = True          # False: every rounding becomes the identity -> the statements below ARE the fp32 oracle (CPU test)
+
+
 def _r(x):
     """round to bf16, straight-through gradient"""
+    if not ROUND:
+        return x
     return x + (x.to(torch.bfloat16).float() - x).detach()
 
 
@@ -16,28 +21,205 @@ def _bn_train(h, gamma, beta, eps):
     return mean, var, gamma / torch.sqrt(var + eps), beta - mean * gamma / torch.sqrt(var + eps)
 
 
-def p3embed_emulated(points, idx, params, k, eps=1e-5):
+class Tape:
+    """How the statements below hand a tensor from one stage to the next.
+
+    Free running (``cap=None``): round to bf16 where the pipeline stores bf16.
+    Link by link (``cap`` = functional._CAPTURE of a pipeline forward): record (name, pipeline tensor, stated value, kind)
+    and CONTINUE FROM THE PIPELINE'S TENSOR -- the value is substituted, the autograd graph of the stated value is kept, so
+    gradients are evaluated at exactly the pipeline's forward tensors (same ReLU masks, same arg-max picks)."""
+
+    def __init__(self, cap=None):
+        self.cap, self.links = cap, []
+
+    def _captured(self, name):
+        grp, key = name.split('.')
+        if grp.startswith('block'):
+            return self.cap['blocks'][int(grp[5:])][key]
+        return self.cap[grp][key]
+
+    def __call__(self, name, v, kind):
+        """kind: 'bf16' (stored bf16), 'att' (bf16, but with roundings of its own inside), 'f32', 'exact'."""
+        if self.cap is None:
+            return _r(v) if kind in ('bf16', 'att') else v
+        got = (self.cap[name] if '.' not in name else self._captured(name)).detach().reshape(v.shape).float()
+        self.links.append((name, got, v.detach(), kind))
+        return v + (got - v).detach()
+
+
+def p3embed_emulated(points, idx, params, k, eps=1e-5, running=None, tape=None):
     """points (B,N,3) f32 cuda, idx (B,S,k) int32; params = dict of fp32 leaf tensors named like the module.
-    Returns tokens [B*S, 256] (fp32) computed the way csrc/embed.hip + the GEMM epilogues do."""
+    Returns tokens [B*S, 256] (fp32) computed the way csrc/embed.hip + the GEMM epilogues do.  ``running`` (eval
+    mode): dict name -> (running_mean, running_var) for '0.2', '1.1', '1.4' instead of the batch statistics."""
+    tape = tape or Tape()
     B, N, _ = points.shape
     S = idx.shape[1]
     b = torch.arange(B, device=points.device).view(B, 1, 1)
     g = points[b, idx.long()]                                    # (B,S,k,3)
     x6 = torch.cat([g, g], dim=-1).reshape(B * S * k, 6)
     W1, W2, b2 = params['0.0.weight'].reshape(256, 6), params['0.1.weight'].reshape(256, 256), params['0.1.bias']
+
+    def fold(h, name, bias=None):
+        """(scale, shift) of the BatchNorm over the rows of h (csrc/embed.hip: embed_fold_kernel / bn_finalize_kernel)."""
+        gamma, beta = params[name + '.weight'], params[name + '.bias']
+        if running is None:
+            mean, var = h.mean(0), h.var(0, unbiased=False)
+            if bias is not None:
+                mean = mean + bias
+        else:
+            mean, var = running[name]
+        sc = gamma / torch.sqrt(var + eps)
+        return sc, (beta - mean * sc) if bias is None else (beta + (bias - mean) * sc)
+
     aeff = W2 @ W1
-    h1 = x6 @ aeff.t() + b2
-    _, _, sc1, sh1 = _bn_train(h1, params['0.2.weight'], params['0.2.bias'], eps)
-    f1 = _r(torch.relu(h1 * sc1 + sh1))                          # F1 stored bf16
-    pooled = f1.view(B * S, k, 256).max(1).values
+    h1 = x6 @ aeff.t()                                           # the conv bias b2 lives in the folded shift
+    sc1, sh1 = fold(h1, '0.2', b2)
+    f1 = tape('embed.F1', torch.relu(h1 * sc1 + sh1), 'bf16')     # F1 stored bf16
+    pooled = tape('embed.pooled', f1.view(B * S, k, 256).max(1).values, 'exact')
     W3 = params['1.0.weight'].reshape(512, 512)
-    u = pooled @ _r(W3[:, :256]).t()
-    h2 = f1 @ _r(W3[:, 256:]).t() + u.repeat_interleave(k, 0)
-    _, _, sc2, sh2 = _bn_train(h2, params['1.1.weight'], params['1.1.bias'], eps)
-    f2 = _r(torch.relu(_r(h2) * sc2 + sh2))
+    u = tape('embed.U', pooled @ _r(W3[:, :256]).t(), 'f32')
+    h2 = f1 @ _r(W3[:, 256:]).t() + u.repeat_interleave(k, 0)    # BatchNorm statistics: from these fp32 accumulators
+    sc2, sh2 = fold(h2, '1.1')
+    f2 = tape('embed.F2', torch.relu(tape('embed.H2', h2, 'bf16') * sc2 + sh2), 'bf16')
     h3 = f2 @ _r(params['1.3.weight'].reshape(256, 512)).t()
-    _, _, sc3, sh3 = _bn_train(h3, params['1.4.weight'], params['1.4.bias'], eps)
-    return torch.relu(_r(h3) * sc3 + sh3).view(B * S, k, 256).max(1).values
+    sc3, sh3 = fold(h3, '1.4')
+    return tape('embed.tok', torch.relu(tape('embed.H3', h3, 'bf16') * sc3 + sh3).view(B * S, k, 256).max(1).values, 'f32')
+
+
+# ------------------------------------------------------------------------------------------------
+# Whole-model statement: every tensor the HIP pipeline stores in bf16 (GEMM operands: weights, LayerNorm outputs, qkv,
+# the softmax numerators P, attention output, GELU output) is rounded here at the same place, everything else (residual
+# stream, LayerNorm / softmax statistics, accumulators) is fp32 -- functional._EncoderFn, csrc/attention.hip,
+# csrc/gemm_tn*.h.
+#
+# Two fp32 implementations of one bf16 pipeline cannot be compared END TO END below the bf16 noise floor: their summation
+# orders differ at 1e-7, that flips ~1e-4 of the next bf16 roundings by one ulp (4e-3 relative), every flip moves a whole
+# row of the following GEMM and flips ~5 % of its roundings, ... -- the difference grows like d -> sqrt(d * ulp) per
+# rounding stage and saturates near the noise floor within one transformer block (measured: tests/tools/debug_matched.py,
+# DESIGN.md section 2).  The whole-model check is therefore made LINK BY LINK (Tape with a capture): every tensor the
+# pipeline hands to its next stage must be a correct bf16 rounding of the stated fp32 value computed from the pipeline's
+# OWN upstream tensors (half an ulp + slack), fp32 hand-offs agree to fp32 accuracy, and the last link is the logits.
+# A kernel-logic error above the slack shows up in exactly one link.
+# ------------------------------------------------------------------------------------------------
+LOG2E = 1.4426950408889634
+KEY_TILE = 64            # csrc/attention.hip: keys are consumed in tiles of 64 rows, ascending
+
+
+def _exp2_fma(s, c, m):
+    """exp2(fma(s, c, -m)) as the kernels evaluate it (one rounding of s*c - m), straight-through for autograd."""
+    exact = (s.detach().double() * c - m.detach().double()).float()
+    smooth = s * c - m
+    return torch.exp2(smooth + (exact - smooth).detach())
+
+
+def attention_emulated(qkv, B, T, H, round_output=True):
+    """qkv [B*T, 3*H*64] (bf16-valued fp32) -> attention output [B*T, H*64].  Online softmax over 64-key tiles in
+    ascending order (csrc/attention.hip: attn_fwd_tile): running maximum m in the base-2 domain c*s, numerators
+    p = exp2(c*s - m) ROUNDED TO bf16 for the P.V product but summed in fp32 for the denominator, accumulator rescaled by
+    exp2(m_old - m_new) per tile, one division at the end, result rounded to bf16."""
+    hd = 64
+    c = float(torch.tensor(hd ** -0.5, dtype=torch.float32) * torch.tensor(LOG2E, dtype=torch.float32))
+    q, k, v = qkv.view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)          # [B,H,T,hd] each
+    s = q @ k.transpose(-1, -2)                                        # [B,H,T,T] fp32 (exact bf16 products)
+    m = torch.full((B, H, T, 1), float('-inf'), device=qkv.device)
+    lsum = torch.zeros(B, H, T, 1, device=qkv.device)
+    o = torch.zeros(B, H, T, hd, device=qkv.device)
+    for k0 in range(0, T, KEY_TILE):
+        st = s[..., k0:k0 + KEY_TILE]
+        mnew = torch.maximum(m, (st.max(-1, keepdim=True).values * c).detach())
+        alpha = torch.exp2(m - mnew)
+        p = _exp2_fma(st, c, mnew)
+        lsum = lsum * alpha + p.sum(-1, keepdim=True)
+        o = o * alpha + _r(p) @ v[:, :, k0:k0 + KEY_TILE]
+        m = mnew
+    out = o * (1.0 / lsum)
+    if round_output:
+        out = _r(out)
+    return out.permute(0, 2, 1, 3).reshape(B * T, H * hd)
+
+
+def _ln(x, w, b, eps):
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+def _gelu(x):
+    return torch.nn.functional.gelu(x)          # exact erf, as the GEMM epilogue (csrc/gemm_tn.h: gelu_f)
+
+
+def encoder_emulated(feats, pos, blocks, norm, H, tape=None):
+    """feats, pos [B,T,D] fp32; blocks: modules with timm's Block layout (norm1, attn.qkv, attn.proj, norm2, mlp.fc1,
+    mlp.fc2); for every block x = blk(x + pos), then the final LayerNorm (functional._EncoderFn: the fc2 epilogue of
+    block l already adds pos for block l+1)."""
+    tape = tape or Tape()
+    B, T, D = feats.shape
+    x, pos2 = feats.reshape(B * T, D), pos.reshape(B * T, D)
+    L = len(blocks)
+    for l, blk in enumerate(blocks):
+        xin = tape(f'block{l}.xin', x + pos2, 'f32') if l == 0 else x
+        ln1 = tape(f'block{l}.ln1', _ln(xin, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps), 'bf16')
+        qkv = tape(f'block{l}.qkv', ln1 @ _r(blk.attn.qkv.weight).t() + blk.attn.qkv.bias, 'bf16')
+        att = tape(f'block{l}.att', attention_emulated(qkv, B, T, H, round_output=False), 'att')
+        x1 = tape(f'block{l}.x1', att @ _r(blk.attn.proj.weight).t() + blk.attn.proj.bias + xin, 'f32')
+        ln2 = tape(f'block{l}.ln2', _ln(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), 'bf16')
+        g = tape(f'block{l}.g', _gelu(ln2 @ _r(blk.mlp.fc1.weight).t() + blk.mlp.fc1.bias), 'bf16')
+        x = g @ _r(blk.mlp.fc2.weight).t() + blk.mlp.fc2.bias + x1
+        x = tape(f'block{l}.xout', x + pos2 if l + 1 < L else x, 'f32')
+    return tape('encoder_out', _ln(x, norm.weight, norm.bias, norm.eps), 'f32').view(B, T, D)
+
+
+def pix4point_emulated(oracle, pts, idx_fps, idx_knn, training=False, tape=None):
+    """Logits of oracle (an oracle.pix4point_oracle.Pix4Point ON THE SAME DEVICE as pts) evaluated the way the HIP
+    pipeline evaluates them.  idx_fps (B,S) int64 / idx_knn (B,S,k) int32 come from the oracle's index functions (the
+    kernels are bit-exact on those: tests/test_gpu_kernels.py).  training=True: batch statistics in the tokenizer's and
+    the head's BatchNorm (set oracle.train() and the dropout probabilities to 0 first).  tape: see Tape."""
+    tape = tape or Tape()
+    pv = oracle.model
+    B, N, _ = pts.shape
+    S, k = idx_fps.shape[1], idx_knn.shape[2]
+    centers = torch.gather(pts, 1, idx_fps.unsqueeze(-1).expand(-1, -1, 3))
+    convs = pv.patch_embed.convs[0]
+    params = {f'{i}.{n}': p for i in (0, 1) for n, p in convs[i].named_parameters()}
+    running = None
+    if not training:
+        running = {f'{i}.{j}': (convs[i][j].running_mean, convs[i][j].running_var) for i, j in ((0, 2), (1, 1), (1, 4))}
+    tok = p3embed_emulated(pts, idx_knn, params, k, eps=convs[0][2].eps, running=running, tape=tape)          # [B*S, 256]
+    xt = _r(tok) @ _r(pv.proj.weight).t() + pv.proj.bias
+    h = _gelu(centers.reshape(B * S, 3) @ pv.pos_embed[0].weight.t() + pv.pos_embed[0].bias)       # fp32 (K = 3: no MFMA)
+    h = tape('streams.h', h, 'f32')
+    pe = _r(h) @ _r(pv.pos_embed[2].weight).t() + pv.pos_embed[2].bias
+    D = xt.shape[1]
+    feats = tape('streams.feats', torch.cat([pv.cls_token.expand(B, -1, -1), xt.view(B, S, D)], dim=1), 'f32')
+    pos = tape('streams.pos', torch.cat([pv.cls_pos.expand(B, -1, -1), pe.view(B, S, D)], dim=1), 'f32')
+    heads = pv.vit_blocks[0].attn.num_heads
+    x = encoder_emulated(feats, pos, list(pv.vit_blocks), pv.norm, heads, tape=tape)
+    glob = torch.cat([x[:, 1:, :].max(dim=1)[0], x[:, 0, :]], dim=1)
+    return oracle.cls_head(glob)
+
+
+def bf16_ulp(v):
+    """spacing of bf16 numbers at |v| (8 significand bits)"""
+    return torch.exp2(torch.floor(torch.log2(v.abs().clamp_min(2.0 ** -100))) - 7)
+
+
+def link_stats(got, want, kind):
+    """One number per link, to be bounded by the caller.
+    'bf16': got is a stored bf16 tensor, want the stated fp32 value before rounding -> worst excess over half an ulp, in
+            ulps, after an absolute slack of 2e-5 x the tensor's rms (fp32 summation order on cancelling sums: 200 times
+            below the bf16 spacing at the rms);
+    'att' : attention output: its roundings of P happen inside the kernel, so one flipped P moves an output by up to
+            2^-8 p |v|: worst |difference| in units of max(ulp(want), 2^-8 rms);
+    'f32' : worst |difference| relative to the tensor's rms;  'exact': number of differing elements."""
+    got, want = got.detach().float(), want.detach().float()
+    d = (got - want).abs()
+    rms = float(want.pow(2).mean().sqrt())
+    if kind == 'exact':
+        return float((d > 0).sum())
+    if kind == 'f32':
+        return float(d.max()) / max(rms, 1e-30)
+    if kind == 'att':
+        return float((d / torch.clamp(bf16_ulp(want), min=rms * 2.0 ** -8)).max())
+    excess = (d - 2e-5 * rms - 0.5 * bf16_ulp(want)).clamp_min(0) / bf16_ulp(want)
+    return float(excess.max())
 
 
 def apf_encoder_emulated(x6, params, G, gs, eps=1e-5, gates=None):

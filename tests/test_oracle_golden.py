@@ -140,3 +140,18 @@ def test_state_dict_names_match_reference_contract():
     assert model.state_dict()['model.patch_embed.convs.0.0.0.weight'].shape == (256, 6, 1, 1)
     assert model.state_dict()['model.patch_embed.convs.0.1.0.weight'].shape == (512, 512, 1, 1)
     assert model.state_dict()['model.patch_embed.convs.0.1.3.weight'].shape == (256, 512, 1, 1)
+
+
+def test_attention_matches_reference_attention_layer(golden_dir):
+    """Row 4's one pinnable piece: O.Attention (the timm attention restated) against the output of the REFERENCE's
+    own AttentionLayer (src/models/apf_utils.py:106-160, recorded by tests/golden/make_golden_apf.py as attn_x / attn_y;
+    same qkv / proj state-dict keys, weights from the same seeded state dict).  timm's Block wiring and Mlp stay
+    unpinned (timm is not vendored)."""
+    from oracle import apf_oracle as A
+    z = np.load(os.path.join(golden_dir, 'apf_layers.npz'))
+    att = O.Attention(192, 3)
+    res = att.load_state_dict(A.seeded_state_dict(A.AttentionLayer(192, 3), seed=1010), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    with torch.no_grad():
+        y = att(torch.from_numpy(z['attn_x'])).numpy()
+    np.testing.assert_allclose(y, z['attn_y'], rtol=1e-5, atol=1e-5)
