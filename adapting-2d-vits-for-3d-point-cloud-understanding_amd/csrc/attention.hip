@@ -1054,6 +1054,7 @@ extern "C" int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B,
     if (check_attn("p4p_attention_fwd", B, T, H, D)) return 1;
     AttnParams p = {};
     p.qkv = (const __bf16*)qkv; p.out = (__bf16*)out; p.lse2 = lse2; p.B = B; p.T = T; p.H = H; p.D = D; p.scale = scale;
+    const bool prof = p4p_prof_begin(3, 4.0 * B * H * (double)T * T * HD, (hipStream_t)stream);      // bench.py: attention forward
     static const bool no_res = getenv("P4P_ATTN_NO_RES") != nullptr;          // A/B switch (tools/ab_bench.sh)
     if (T <= RES_ROWS - 31 && T >= 64 && !no_res)
         hipLaunchKernelGGL(attn_fwd_res_kernel, dim3(B * H), dim3(RES_NW * 64), 0, (hipStream_t)stream, p);
@@ -1070,6 +1071,7 @@ extern "C" int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B,
         else
             hipLaunchKernelGGL(attn_fwd_kernel, attn_grid(B, T, H), dim3(ATT_THREADS), 0, (hipStream_t)stream, p);
     }
+    if (prof) p4p_prof_end((hipStream_t)stream);
     P4P_LAUNCH_CHECK();
     return 0;
 }
@@ -1094,6 +1096,12 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
     P4P_CHECK(qkv && o && dout && lse2 && delta && dqkv, "p4p_attention_bwd: null pointer");
     if (check_attn("p4p_attention_bwd", B, T, H, D)) return 1;
     hipStream_t st = (hipStream_t)stream;
+    // bench.py: the whole backward (delta + dQ + dK/dV launches) as one bracket, 2.5 x the forward's FLOPs
+    struct ProfScope {
+        hipStream_t s; bool on;
+        ProfScope(double fl, hipStream_t s_) : s(s_), on(p4p_prof_begin(4, fl, s_)) {}
+        ~ProfScope() { if (on) p4p_prof_end(s); }
+    } prof_scope(10.0 * B * H * (double)T * T * HD, st);
     const bool res_dkdv = attn_resident_dkdv(T);
     const bool res = attn_resident(T) && (res_dkdv || !colsum_partial);
     static const int env_dq_qt = getenv("P4P_ATTN_DQ_QT") ? atoi(getenv("P4P_ATTN_DQ_QT")) : 0;       // A/B switch (tools/attn_ab.py)

@@ -15,7 +15,8 @@ extern "C" const char* p4p_last_error(void) { return g_err; }
 extern "C" int p4p_abi_version(void) { return 1; }
 
 // ---- optional launch profiler: HIP events around exactly one kernel launch (bench.py's roofline) --------
-// kind 1 = weight-gradient GEMM main kernel, kind 2 = gemm_tn main kernel.  Events sit on the launch stream.
+// kind 1 = weight-gradient GEMM main kernel, kind 2 = gemm_tn main kernel, kind 3 = attention forward, kind 4 = attention
+// backward (its two or three launches in one bracket).  Events sit on the launch stream.
 #include <vector>
 struct ProfRec { hipEvent_t a, b; double flops; };
 static int g_prof_kind = 0;

@@ -218,7 +218,11 @@ __global__ __launch_bounds__(BK_ * 2, 2) void gemm_wgrad3_kernel(W3Params p) {
         char* tmp = cur; cur = nxt; nxt = nn; nn = tmp;                                   \
     }
     int kt = 0;
-    for (; kt + 4 < nk; kt += 2) {
+    // W3_FULL(kt + 1) stages step kt + 4 WITHOUT the row check: the loop must stop before that is the split's last
+    // step, which in the last split may be the ragged end of the matrix (M % 32 rows).  (With `kt + 4 < nk` an odd
+    // step count in the last split read up to 31 rows past the end of G and A -- found by the ViT-L / N=8192
+    // reproducibility test: M = 16392, 101 steps.)
+    for (; kt + 5 < nk; kt += 2) {
         W3_FULL(kt, f0, f1)
         W3_FULL(kt + 1, f1, f0)
     }

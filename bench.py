@@ -97,7 +97,9 @@ class Stepper:
         self.fused_opt = isinstance(self.opt, FusedAdamW)
         self.crit = torch.nn.CrossEntropyLoss()
 
-    def step(self, pts, labels, start):
+    def step(self, pts, labels, start, optim=True):
+        """optim=False: the metric's literal 'fwd+bwd' (zero_grad + forward + CE + backward + gradient all-reduce),
+        reference src/train/pix4point_trainer.py:162-165; optim=True adds clip_grad_norm_ + AdamW (:166-167)."""
         if self.reducer is not None:
             self.reducer.zero_grad()
         else:
@@ -106,6 +108,8 @@ class Stepper:
         loss.backward()
         if self.reducer is not None:
             self.reducer.finish()
+        if not optim:
+            return loss
         if self.fused_opt:
             self.opt.step(max_norm=10)               # clip_grad_norm_ + AdamW in three launches (p4p_amd.optim)
         else:
@@ -133,7 +137,7 @@ class ApfStepper:
         self.opt = FusedAdamW(self.model.parameters(), lr=5e-4, weight_decay=5e-2)
         self.crit = torch.nn.CrossEntropyLoss(label_smoothing=0.3)
 
-    def step(self, pts, labels, start):
+    def step(self, pts, labels, start, optim=True):
         if self.reducer is not None:
             self.reducer.zero_grad()
         else:
@@ -142,20 +146,39 @@ class ApfStepper:
         loss.backward()
         if self.reducer is not None:
             self.reducer.finish()
-        self.opt.step()
+        if optim:
+            self.opt.step()
         return loss
 
 
+PROF_KINDS = ((1, 'gemm_wgrad3_kernel'), (2, 'gemm_tn (all tile configs / epilogues)'),
+              (3, 'attention forward'), (4, 'attention backward (dQ + dK/dV launches)'))
+
+
+def _pmc_traffic(kernel_tag):
+    """HBM-side bytes per launch of the dominant kernel.  PMC counters need rocprofv3 AROUND the process, so this is the
+    committed measurement of this same command (profiles/rNN_pmc_<tag>.json: FETCH_SIZE x2 + WRITE_SIZE, separate --pmc
+    passes, as MI355X_MICROARCH.md prescribes), newest round first; None when no such file exists."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_pmc_{kernel_tag}.json')), reverse=True)
+    for f in files:
+        with open(f) as fh:
+            j = json.load(fh)
+        return (j['fetch_bytes_per_launch'] + j['write_bytes_per_launch'],
+                f'bytes/launch, rocprofv3 PMC ({os.path.relpath(f, ROOT)}), not collected in this run')
+    return None, None
+
+
 def instrumented_roofline(stepper, batch, steps, measure=True):
-    """Roofline of the dominant kernel, measured live: the library brackets exactly that kernel's launch with
-    HIP events on the launch stream (include/p4p_hip.h: p4p_prof_enable / p4p_prof_collect) during `steps`
-    extra training steps; algorithmic FLOPs = 2 M N K per launch.  Kind 1 = weight-gradient GEMM main kernel
-    (gemm_wgrad3_kernel, the kernel with the largest total time in profiles/), kind 2 = all gemm_tn launches."""
+    """Rooflines measured live: the library brackets exactly the launches of one kind with HIP events on the launch
+    stream (include/p4p_hip.h: p4p_prof_enable / p4p_prof_collect) during `steps` extra training steps per kind;
+    algorithmic FLOPs = 2 M N K per GEMM launch, 4 B H T^2 64 per attention forward (x 2.5 backward).  The headline entry
+    is the kernel with the largest total time (the weight-gradient GEMM main kernel, as in profiles/)."""
     import ctypes
     from p4p_amd import _lib
     lib = _lib.lib()
     res = {}
-    for kind, name in ((1, 'gemm_wgrad3_kernel'), (2, 'gemm_tn (all tile configs / epilogues)')):
+    for kind, name in PROF_KINDS:
         if measure:
             lib.p4p_prof_enable(kind)
         for _ in range(steps):                      # EVERY rank takes these steps: they contain the gradient all-reduce
@@ -169,20 +192,13 @@ def instrumented_roofline(stepper, batch, steps, measure=True):
         res[kind] = {'name': name, 'ms': out[0], 'launches': out[1], 'flops': out[2]}
     if not measure:
         return None
-    agg_fl = sum(r['flops'] for r in res.values())
-    agg_ms = sum(r['ms'] for r in res.values())
-    dom = max(res.values(), key=lambda r: r['ms'] if r['name'].startswith('gemm_wgrad3') else 0)
+    gemms = [res[1], res[2]]
+    agg_fl = sum(r['flops'] for r in gemms)
+    agg_ms = sum(r['ms'] for r in gemms)
+    dom = res[1]
     ach = dom['flops'] / (dom['ms'] * 1e-3) * 1e-12
-    # HBM-side bytes per launch of the same kernel: PMC counters need rocprofv3 around the process, so the figure is
-    # the committed measurement of this command (profiles/r01_pmc_wgrad.json: FETCH_SIZE x2 + WRITE_SIZE, separate
-    # passes, as MI355X_MICROARCH.md prescribes); null when the file is not there
-    traffic, traffic_note = None, None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_wgrad.json')
-    if os.path.exists(pmc):
-        with open(pmc) as fh:
-            j = json.load(fh)
-        traffic = j['fetch_bytes_per_launch'] + j['write_bytes_per_launch']
-        traffic_note = 'bytes/launch, rocprofv3 PMC (profiles/r01_pmc_wgrad.json), not collected in this run'
+    traffic, traffic_note = _pmc_traffic('wgrad')
+    tf = lambda r: r['flops'] / (r['ms'] * 1e-3) * 1e-12 if r['ms'] > 0 else None
     return {
         'bound': 'mfma', 'kernel': dom['name'], 'achieved': ach, 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
         'frac': ach / PEAK_BF16_TFLOPS, 'traffic': traffic, 'traffic_note': traffic_note,
@@ -190,7 +206,10 @@ def instrumented_roofline(stepper, batch, steps, measure=True):
         'flop_per_launch': dom['flops'] / dom['launches'], 'ms_per_step': dom['ms'] / steps,
         'all_mfma_gemms': {'achieved': agg_fl / (agg_ms * 1e-3) * 1e-12,
                            'frac': agg_fl / (agg_ms * 1e-3) * 1e-12 / PEAK_BF16_TFLOPS, 'ms_per_step': agg_ms / steps},
-        'per_kernel': {r['name']: {'TFLOP/s': r['flops'] / (r['ms'] * 1e-3) * 1e-12, 'ms_per_step': r['ms'] / steps,
+        'attention': {'fwd_TFLOPs': tf(res[3]), 'bwd_TFLOPs': tf(res[4]),
+                      'fwd_frac': (tf(res[3]) or 0) / PEAK_BF16_TFLOPS, 'bwd_frac': (tf(res[4]) or 0) / PEAK_BF16_TFLOPS,
+                      'ms_per_step': (res[3]['ms'] + res[4]['ms']) / steps},
+        'per_kernel': {r['name']: {'TFLOP/s': tf(r), 'ms_per_step': r['ms'] / steps,
                                    'launches_per_step': r['launches'] / steps} for r in res.values()},
     }
 
@@ -311,6 +330,57 @@ def cpu_baseline_apf(args, budget_s=25.0):
             'torch_threads': torch.get_num_threads()}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 outside a launcher: start one rank per GPU with torch.distributed.run as a
+    CHILD process (this process has not touched the GPU yet and never will) and pass its exit code on."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log('spawning: ' + ' '.join(cmd))
+    return subprocess.call(cmd, env=env)
+
+
+def timed_steps(stepper, batch, steps, fence, distributed, device, optim=True):
+    """EXACTLY `steps` steps between two fences (barrier + device synchronize); seconds, max over ranks, and every
+    rank's own time."""
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = stepper.step(*batch, optim=optim)
+    fence()
+    elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
+    if distributed:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(allt, t)
+        per_rank = [float(x.item()) for x in allt]
+        elapsed = max(per_rank)
+    return elapsed, per_rank, float(loss.detach())
+
+
+def allreduce_exposed_ms(stepper, batch, steps=3):
+    """Diagnostic for multi-GPU runs: how long the step waits in GradReducer.finish() after the backward has been
+    drained (device-synchronised on both sides, so this pass is not part of any reported throughput)."""
+    tot = 0.0
+    for _ in range(steps):
+        stepper.reducer.zero_grad()
+        loss = stepper.crit(stepper.model(batch[0], batch[2]), batch[1])
+        loss.backward()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        stepper.reducer.finish()
+        torch.cuda.synchronize()
+        tot += time.perf_counter() - t0
+        stepper.opt.step(max_norm=10) if getattr(stepper, 'fused_opt', False) else stepper.opt.step()
+    return tot / steps * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -321,18 +391,31 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='clouds per GPU (default 256; apf: 128)')
     ap.add_argument('--points', type=int, default=None, help='points per cloud (default 1024; apf: 2048)')
     ap.add_argument('--vit', default=None)
-    ap.add_argument('--dim', type=int, default=768)
+    ap.add_argument('--dim', type=int, default=None)
     ap.add_argument('--classes', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-north-star', action='store_true',
+                    help='skip the extra N=2048, B=256 measurement (the point north_star states its targets at)')
     args = ap.parse_args()
     apf = args.workload == 'apf'
+    default_config = args.batch is None and args.points is None and args.vit is None and not apf
     args.batch = args.batch or (128 if apf else 256)
     args.points = args.points or (2048 if apf else 1024)
     args.vit = args.vit or ('vit_base_patch16_224' if apf else 'vit_base_patch16_384')
     args.classes = args.classes or (15 if apf else 40)
+    from p4p_amd.vit import parse_model_name          # imports torch only: no GPU call before the rank check below
+    vd, vl, vh, _, _ = parse_model_name(args.vit)
+    args.dim = args.dim or vd
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
+    world_env = os.environ.get('WORLD_SIZE')
+    if world_env is None and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    world = int(world_env or '1')
+    if world != args.gpus:
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU '
+              f'(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)', file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     distributed = world > 1
@@ -355,38 +438,56 @@ def main():
     stepper = (ApfStepper if apf else Stepper)(args, device, distributed)
     batch = synthetic_batch(args.batch, args.points, args.classes, 1234 + rank, device)
 
-    log(f'rank {rank}/{world}: model built, warm-up {args.warmup} steps')
-    for _ in range(args.warmup):
-        stepper.step(*batch)
-
     def fence():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = stepper.step(*batch)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    loss_val = float(loss.detach())
+    log(f'rank {rank}/{world}: model built, warm-up {args.warmup} steps')
+    for _ in range(args.warmup):
+        stepper.step(*batch)
+    elapsed, per_rank, loss_val = timed_steps(stepper, batch, args.steps, fence, distributed, device)
     log(f'timed region: {args.steps} steps in {elapsed:.3f} s')
+    # the metric's literal "fwd+bwd" (no clip / AdamW), SURVEY.md section 8d's first figure: the same K steps again
+    fb_elapsed, _, _ = timed_steps(stepper, batch, args.steps, fence, distributed, device, optim=False)
 
     roof = None
     if not args.no_roofline:
         # all ranks run the instrumented steps (a step holds collectives); only rank 0 brackets its kernels with events
-        roof = instrumented_roofline(stepper, batch, max(2, min(args.steps, 5)), measure=rank == 0)
+        roof = instrumented_roofline(stepper, batch, max(2, min(args.steps, 3)), measure=rank == 0)
     if rank == 0 and roof is not None:
         if apf:
             roof['index_ops'] = index_ops_roofline(args.batch, args.points, 196, 32, device)
         else:
             roof['index_ops'] = index_ops_roofline(args.batch, args.points, args.points // 4, 16, device)
         log('instrumented roofline pass done')
+    ar_wait = allreduce_exposed_ms(stepper, batch) if distributed else None
+
+    # ---- the point north_star states its utilisation targets at: N=2048, B=256, ViT-B/12, one GPU
+    ns = None
+    if default_config and world == 1 and not args.no_north_star:
+        nb, npts = 256, 2048
+        ns_batch = synthetic_batch(nb, npts, args.classes, 4321, device)
+        for _ in range(2):
+            stepper.step(*ns_batch)
+        ns_steps = 10
+        ns_el, _, _ = timed_steps(stepper, ns_batch, ns_steps, fence, False, device)
+        ns_fb, _, _ = timed_steps(stepper, ns_batch, 5, fence, False, device, optim=False)
+        ns_roof = instrumented_roofline(stepper, ns_batch, 2) if not args.no_roofline else None
+        fl = flop_per_cloud(npts, vd, vl)
+        v = nb * ns_steps / ns_el
+        ns = {'workload': f'Pix4Point {args.vit} N={npts} k=16, batch {nb}, 1 GPU (same step as the headline line)',
+              'clouds_per_sec': v, 'ms_per_step': ns_el / ns_steps * 1e3, 'steps': ns_steps,
+              'algorithmic_gflop_per_cloud': fl * 1e-9, 'algorithmic_tflops': v * fl * 1e-12,
+              'mfma_frac_whole_step': v * fl * 1e-12 / PEAK_BF16_TFLOPS,
+              'fwd_bwd_only': {'clouds_per_sec': nb * 5 / ns_fb, 'ms_per_step': ns_fb / 5 * 1e3}}
+        if ns_roof:
+            ns['gemm_wgrad_TFLOPs'] = ns_roof['achieved']
+            ns['all_mfma_gemms'] = ns_roof['all_mfma_gemms']
+            ns['attention'] = ns_roof['attention']
+            ns['index_ops'] = index_ops_roofline(nb, npts, npts // 4, 16, device)
+        log('north-star point (N=2048, B=256) done')
+        del ns_batch
     if distributed:
         dist.barrier()
     cpu = None
@@ -396,8 +497,6 @@ def main():
     if rank == 0:
         clouds = args.batch * world * args.steps
         value = clouds / elapsed
-        from p4p_amd.vit import parse_model_name
-        vd, vl, vh, _, _ = parse_model_name(args.vit)
         fl = apf_flop_per_cloud(E=vd, L=vl) if apf else flop_per_cloud(args.points, vd, vl)
         fam = {192: 'ViT-Ti', 384: 'ViT-S', 768: 'ViT-B', 1024: 'ViT-L'}.get(vd, f'ViT(D={vd})')
         out = {
@@ -412,7 +511,13 @@ def main():
                        'final_loss': loss_val, 'algorithmic_gflop_per_cloud': fl * 1e-9},
             'algorithmic_tflops_per_gpu': (value / world * fl * 1e-12) if fl else None,
             'mfma_frac_whole_step': (value / world * fl * 1e-12 / PEAK_BF16_TFLOPS) if fl else None,
+            # SURVEY.md section 8d's first figure: zero_grad + forward + CE + backward (+ all-reduce), no clip / AdamW
+            'fwd_bwd_only': {'value': clouds / fb_elapsed, 'unit': 'point-clouds/sec',
+                             'ms_per_step': fb_elapsed / args.steps * 1e3, 'steps': args.steps},
+            'per_rank_ms_per_step': [t / args.steps * 1e3 for t in per_rank],
         }
+        if ar_wait is not None:
+            out['allreduce_exposed_ms'] = ar_wait
         if apf:
             out['metric'] = f'point-clouds/sec fwd+bwd (train step), APF adapter path N={args.points} {fam} frozen'
             out['config']['workload'] = (f'AdaptPointFormer {args.vit} (D={vd}, {vl} frozen blocks + adapters), 196 groups of 32, '
@@ -422,6 +527,8 @@ def main():
                                          'transformer 2x fwd')
         if roof:
             out['roofline'] = roof
+        if ns:
+            out['north_star_point'] = ns
         if cpu:
             out['cpu_baseline'] = cpu
         print(json.dumps(out))

@@ -155,7 +155,8 @@ int p4p_embed_stage1_bwd(const float* points, const float* feats, const int32_t*
                          float beta_acc, int B, int N, int S, int k, int C1, void* stream);
 
 /* ---- measurement aid (bench.py roofline): HIP events on the launch stream around exactly the main kernel of
- * kind 1 (weight-gradient GEMM) or 2 (gemm_tn).  collect(): out[0] = total ms, out[1] = launches, out[2] = FLOPs. */
+ * kind 1 (weight-gradient GEMM), 2 (gemm_tn), 3 (attention forward), 4 (attention backward: its launches in one bracket).
+ * collect(): out[0] = total ms, out[1] = launches, out[2] = algorithmic FLOPs (2MNK; attention 4 B H T^2 64, x2.5 backward). */
 int p4p_prof_enable(int kind);
 int p4p_prof_collect(double* out);
 /* experiment switches (tools/gemm_bench.py): tile configuration overrides, 0 = automatic */

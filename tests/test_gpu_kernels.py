@@ -354,7 +354,8 @@ def _attn_ref(qkv, B, T, H):
 
 
 @pytest.mark.parametrize('B,T,H', [(2, 1, 1), (2, 17, 3), (3, 64, 2), (2, 65, 3), (2, 100, 2), (1, 129, 1), (2, 192, 2),
-                                   (2, 256, 2), (2, 257, 3), (2, 258, 1), (1, 513, 2), (1, 2049, 1)])
+                                   (2, 256, 2), (2, 257, 3), (2, 258, 1), (1, 513, 2), (1, 2049, 1),
+                                   (2, 2049, 16)])          # BASELINE configs[4]: ViT-L heads at N=8192
 def test_attention_fwd_bwd(B, T, H):
     D = 64 * H
     g = torch.Generator().manual_seed(T)
@@ -364,6 +365,12 @@ def test_attention_fwd_bwd(B, T, H):
     ref = _attn_ref(qr, B, T, H)
     # tolerance: P and the output are rounded to bf16 (2^-8); values are O(1)
     torch.testing.assert_close(out.float(), ref, rtol=2e-2, atol=2e-2)
+    # against the rounding-matched statement (same tile order, P rounded to bf16): a correct rounding of it, up to the
+    # P roundings inside the kernel (tests/emulate.py: link_stats 'att'; these inputs make a PEAKED softmax, where one
+    # flipped numerator moves an output by up to 2^-9 p |v|: measured 0.63, against 0.51 on the model's own activations)
+    from tests import emulate as E
+    with torch.no_grad():
+        assert E.link_stats(out, E.attention_emulated(qkv.float(), B, T, H, round_output=False), 'att') <= (1.0 if T < 1024 else 2.0)
     dout = torch.randn(B * T, D, generator=g).to(torch.bfloat16).to(DEV)
     ref.backward(dout.float())
     dqkv = ops.attention_bwd(qkv, out, dout, lse, B, T, H)
@@ -397,6 +404,22 @@ def test_gemm_wgrad_ring_kernel_exact_on_integer_data(M, N, K):
     assert torch.equal(db, g.float().sum(0))
     acc = ops.gemm_wgrad(g, a, out=dw.clone(), beta=1.0)
     assert torch.equal(acc, 2 * want)
+
+
+@pytest.mark.parametrize('M,N,K', [(11009, 768, 256), (4099, 3072, 1024), (32771, 512, 128)])
+def test_gemm_wgrad_ring_kernel_never_reads_past_a_ragged_end(M, N, K):
+    """Regression (round 2): with an ODD number (>= 5) of 32-row steps in the last M-split and M % 32 != 0 the unchecked
+    fast staging path of gemm_wgrad3_kernel fetched the ragged last step, i.e. up to 31 rows past the end of both
+    operands (first seen as a run-to-run difference of the ViT-L / N=8192 weight gradients, M = 16392).  The operands
+    here are the leading rows of larger buffers whose remaining rows are poisoned."""
+    gf = torch.full((M + 64, N), 64.0, dtype=torch.bfloat16, device=DEV)
+    af = torch.full((M + 64, K), 64.0, dtype=torch.bfloat16, device=DEV)
+    gf[:M] = (_int_bf16((M, N), -1, 1, 5).to(DEV) * (torch.rand(M, N, device=DEV) < 0.1)).to(torch.bfloat16)
+    af[:M] = _int_bf16((M, K), -2, 2, 6).to(DEV)
+    g, a = gf[:M], af[:M]
+    assert g.is_contiguous() and a.is_contiguous()
+    dw = ops.gemm_wgrad(g, a)
+    assert torch.equal(dw, g.float().t() @ a.float())
 
 
 def test_global_feat_matches_torch():
