@@ -155,7 +155,7 @@ class Group(nn.Module):
         return fps_idx, knn_idx, ops.morton_order(center)
 
     def forward(self, x: torch.Tensor, xyz: torch.Tensor, start_idx: Optional[torch.Tensor] = None):
-        """x (B,N,3), xyz (B,N,3) -> (neighborhood (B,G,gs,6) f32, center (B,G,3)), Morton order."""
+        """x (B,N,C), xyz (B,N,3) -> (neighborhood (B,G,gs,2C) f32, center (B,G,3)), Morton order (C = 3 or 4)."""
         fps_idx, knn_idx, order = self.indices(xyz, start_idx)
         nb, _, center = ops.apf_group(x.contiguous().float(), fps_idx, knn_idx, order, want_f32=True, want_x0=False)
         return nb, center
@@ -166,8 +166,10 @@ class Encoder(nn.Module):
 
     def __init__(self, encoder_channel: int, in_channel: int):
         super().__init__()
-        if in_channel != 6:
-            raise NotImplementedError('the HIP encoder is built for in_channel=6 (xyz groups, the reference configuration)')
+        if in_channel not in (6, 8):
+            raise NotImplementedError('the HIP encoder is built for in_channel = 6 (xyz groups) and 8 (xyz + height, the '
+                                      "reference's shipped configuration: train_apf.py:5 in_channels=4, apf.py:293)")
+        self.in_channel = in_channel
         if encoder_channel % 64:
             raise NotImplementedError('encoder_channel must be a multiple of 64 (GEMM K granularity)')
         self.encoder_channel = encoder_channel
@@ -184,9 +186,9 @@ class Encoder(nn.Module):
 
     def get_features(self, point_groups: torch.Tensor) -> torch.Tensor:
         B, G, n, C = point_groups.shape
-        if C != 6:
-            raise RuntimeError(f'point_groups: expected 6 channels, got {C}')
-        x0 = FA.split_hi_lo_input(point_groups.reshape(B * G * n, 6).float())
+        if C != self.in_channel:
+            raise RuntimeError(f'point_groups: expected {self.in_channel} channels, got {C}')
+        x0 = FA.split_hi_lo_input(point_groups.reshape(B * G * n, C).float())
         return self.encode_rows(x0, B, G, n)
 
     def forward(self, point_groups: torch.Tensor) -> torch.Tensor:
@@ -202,10 +204,11 @@ class PointNet(nn.Module):
         self.encoder = Encoder(embed_dim, in_channel)
 
     def forward(self, x: torch.Tensor, start_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if x.shape[-1] != 3:
-            raise NotImplementedError('built for in_channels=3 (xyz only), the reference configuration')
+        if 2 * x.shape[-1] != self.encoder.in_channel:
+            raise RuntimeError(f'PointNet: {x.shape[-1]} input channels, but the encoder was built for '
+                               f'{self.encoder.in_channel // 2} (in_channels of AdaptPointFormer)')
         x = x.contiguous().float()
-        fps_idx, knn_idx, order = self.group.indices(x, start_idx)
+        fps_idx, knn_idx, order = self.group.indices(x[:, :, :3], start_idx)                 # apf.py:210: xyz = x[:,:,:3]
         _, x0, _ = ops.apf_group(x, fps_idx, knn_idx, order, want_center=False)
         return self.encoder.encode_rows(x0, x.shape[0], self.group.num_group, self.group.group_size)
 

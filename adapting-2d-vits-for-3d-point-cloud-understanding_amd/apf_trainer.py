@@ -74,13 +74,26 @@ class APFTrainer(Pix4PointTrainer):
         # rotate_point_cloud for training; center_and_normalize_point_cloud for testing) on the device batch
         gen = [None]
 
+        use_height = bool(c.get('use_height', False))
+        want_c = self.model_config.get('in_channels', 3)
+        if want_c != (4 if use_height else 3):
+            raise ValueError(f"model_config['in_channels']={want_c} does not match dataset_config['use_height']={use_height} "
+                             '(the reference appends one height column, src/data/scanobjectnn.py:218-224)')
+
+        def with_height(xyz, heights):
+            return torch.cat([xyz, heights], dim=-1) if use_height else xyz
+
         def train_aug(points):
             if gen[0] is None:
                 gen[0] = torch.Generator(device=points.device).manual_seed(1234 + self.rank)
             points = GA.scale_point_cloud(points, generator=gen[0])
-            return GA.rotate_point_cloud(GA.normalize_point_cloud(points), generator=gen[0])
+            xyz, heights = GA.center_and_normalize_point_cloud(points)       # heights of the scaled, un-normalised cloud
+            return with_height(GA.rotate_point_cloud(xyz, generator=gen[0]), heights)
+
+        def test_aug(points):
+            return with_height(*GA.center_and_normalize_point_cloud(points))
         self.train_augment = train_aug
-        self.test_augment = GA.normalize_point_cloud
+        self.test_augment = test_aug
 
     # ---- reference :164-183
     def _init_optimizer(self) -> None:

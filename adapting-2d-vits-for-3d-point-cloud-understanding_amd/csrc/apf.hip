@@ -106,6 +106,7 @@ extern "C" int p4p_morton_order_f32(const float* centers, int32_t* order, int32_
 //   center  [B,G,3]     fp32  - centres in Morton order
 // One thread per output point row; 128 B per row written as 8 x 16 B.
 // ---------------------------------------------------------------------------------------------
+template <int C>
 __global__ void apf_group_kernel(const float* __restrict__ x, const int64_t* __restrict__ fps_idx,
                                  const int32_t* __restrict__ knn_idx, const int32_t* __restrict__ order,
                                  float* __restrict__ nb_f32, __bf16* __restrict__ x0, float* __restrict__ center, int N,
@@ -119,56 +120,59 @@ __global__ void apf_group_kernel(const float* __restrict__ x, const int64_t* __r
     const int src = order[b * G + gq];
     const long long c = fps_idx[b * G + src];
     const int n = knn_idx[(b * G + src) * gs + j];
-    const float* pc = x + (b * N + c) * 3;
-    const float* pn = x + (b * N + n) * 3;
-    float six[6];
+    const float* pc = x + (b * N + c) * C;
+    const float* pn = x + (b * N + n) * C;
+    float f[2 * C];                      // [x[nbr] - x[centre] (C), x[centre] (C)]   (apf.py:83-95)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        six[3 + i] = pc[i];
-        six[i] = __fsub_rn(pn[i], pc[i]);
+    for (int i = 0; i < C; ++i) {
+        f[C + i] = pc[i];
+        f[i] = __fsub_rn(pn[i], pc[i]);
     }
     if (nb_f32) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) nb_f32[r * 6 + i] = six[i];
+        for (int i = 0; i < 2 * C; ++i) nb_f32[r * (2 * C) + i] = f[i];
     }
     if (center && j == 0) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) center[bg * 3 + i] = pc[i];
     }
     if (x0) {
-        __bf16 row[24];
+        // [hi (2C) | lo (2C) | hi (2C) | 0 ...]: partner of functional_apf._split_hi_lo_weight's [W_hi | W_hi | W_lo | 0]
+        __bf16 row[64];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const __bf16 h = f2bf(six[i]);
+        for (int i = 0; i < 64; ++i) row[i] = f2bf(0.f);
+#pragma unroll
+        for (int i = 0; i < 2 * C; ++i) {
+            const __bf16 h = f2bf(f[i]);
             row[i] = h;
-            row[6 + i] = f2bf(six[i] - bf2f(h));
-            row[12 + i] = h;
+            row[2 * C + i] = f2bf(f[i] - bf2f(h));
+            row[4 * C + i] = h;
         }
-#pragma unroll
-        for (int i = 18; i < 24; ++i) row[i] = f2bf(0.f);
         bf16x8* dst = reinterpret_cast<bf16x8*>(x0 + r * 64);
-        const bf16x8 zero = {};
 #pragma unroll
-        for (int v = 0; v < 3; ++v) {
+        for (int v = 0; v < 8; ++v) {
             bf16x8 w;
 #pragma unroll
             for (int i = 0; i < 8; ++i) w[i] = row[8 * v + i];
             dst[v] = w;
         }
-#pragma unroll
-        for (int v = 3; v < 8; ++v) dst[v] = zero;
     }
 }
 
 extern "C" int p4p_apf_group(const float* x, const int64_t* fps_idx, const int32_t* knn_idx, const int32_t* order,
-                             float* nb_f32, void* x0_bf16, float* center, int B, int N, int G, int gs, void* stream) {
+                             float* nb_f32, void* x0_bf16, float* center, int B, int N, int C, int G, int gs, void* stream) {
     P4P_CHECK(x && fps_idx && knn_idx && order, "p4p_apf_group: null pointer");
     P4P_CHECK(nb_f32 || x0_bf16 || center, "p4p_apf_group: no output requested");
     P4P_CHECK(B >= 0 && N >= 1 && G >= 1 && gs >= 1, "p4p_apf_group: bad sizes B=%d N=%d G=%d gs=%d", B, N, G, gs);
+    P4P_CHECK(C == 3 || C == 4, "p4p_apf_group: built for C = 3 (xyz) and C = 4 (xyz + height), got C=%d", C);
     const long long total = (long long)B * G * gs;
     if (total == 0) return 0;
-    hipLaunchKernelGGL(apf_group_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, fps_idx, knn_idx,
-                       order, nb_f32, (__bf16*)x0_bf16, center, N, G, gs, total);
+    if (C == 3)
+        hipLaunchKernelGGL(apf_group_kernel<3>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, fps_idx,
+                           knn_idx, order, nb_f32, (__bf16*)x0_bf16, center, N, G, gs, total);
+    else
+        hipLaunchKernelGGL(apf_group_kernel<4>, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, x, fps_idx,
+                           knn_idx, order, nb_f32, (__bf16*)x0_bf16, center, N, G, gs, total);
     P4P_LAUNCH_CHECK();
     return 0;
 }

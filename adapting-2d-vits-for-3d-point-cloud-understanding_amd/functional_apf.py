@@ -59,22 +59,25 @@ def _adapter_up_operands(uw, ub, scale):
 
 
 def _split_hi_lo_weight(W1):
-    """[C,6] fp32 -> bf16 [C,64] = [W_hi, W_hi, W_lo, 0]: partner of the x0 layout of p4p_apf_group."""
+    """[C,c] fp32 (c = 6 or 8 input channels) -> bf16 [C,64] = [W_hi, W_hi, W_lo, 0]: partner of the x0 layout of
+    p4p_apf_group."""
     C = W1.shape[0]
-    w = W1.detach().reshape(C, 6)
+    w = W1.detach().reshape(C, -1)
+    c = w.shape[1]
     hi = w.bfloat16()
     lo = (w - hi.float()).bfloat16()
     out = torch.zeros(C, 64, dtype=torch.bfloat16, device=w.device)
-    out[:, 0:6], out[:, 6:12], out[:, 12:18] = hi, hi, lo
+    out[:, 0:c], out[:, c:2 * c], out[:, 2 * c:3 * c] = hi, hi, lo
     return out
 
 
 def split_hi_lo_input(pg):
-    """[P,6] fp32 -> bf16 [P,64] = [x_hi, x_lo, x_hi, 0] (what p4p_apf_group writes directly on the fused path)."""
+    """[P,c] fp32 -> bf16 [P,64] = [x_hi, x_lo, x_hi, 0] (what p4p_apf_group writes directly on the fused path)."""
+    c = pg.shape[1]
     hi = pg.bfloat16()
     lo = (pg - hi.float()).bfloat16()
     out = torch.zeros(pg.shape[0], 64, dtype=torch.bfloat16, device=pg.device)
-    out[:, 0:6], out[:, 6:12], out[:, 12:18] = hi, lo, hi
+    out[:, 0:c], out[:, c:2 * c], out[:, 2 * c:3 * c] = hi, lo, hi
     return out
 
 
@@ -117,7 +120,7 @@ class _ApfEncoderFn(torch.autograd.Function):
                 m.num_batches_tracked += 1
         if _CAPTURE is not None:
             _CAPTURE.update(F1=F1, F2=F2, F4=F4, arg3=arg3, arg5=arg5)
-        ctx.training, ctx.dims = training, (G, gs, C1, C2, E)
+        ctx.training, ctx.dims, ctx.cin = training, (G, gs, C1, C2, E), W1.shape[1]
         ctx.save_for_backward(x0, H1, F1, sc1, sh1, mean1, is1, H2, F2, sc2, sh2, mean2, is2, f, fg, arg3, H4, F4, sc4,
                               sh4, mean4, is4, arg5, W2T, W3T, W4aT, W4bT, W5T)
         return tok
@@ -155,11 +158,12 @@ class _ApfEncoderFn(torch.autograd.Function):
         del dF2
         s1 = ops.relu_bn_bwd_(dF1, H1, sc1, sh1, mean1, is1)
         dW1p = ops.gemm_wgrad(dF1, x0)                                          # [C1, 64]: hi and lo input columns
-        dW1 = dW1p[:, 0:6] + dW1p[:, 6:12]
+        cin = ctx.cin
+        dW1 = dW1p[:, 0:cin] + dW1p[:, cin:2 * cin]
         zeros = lambda n: torch.zeros(n, dtype=torch.float32, device=dtok.device)   # a bias in front of train-mode BN
         dW4 = torch.cat([dW4a, dW4b], dim=1)
         return (None, None, None, None, None, None,
-                dW1.reshape(C1, 6, 1), zeros(C1), s1[1].clone(), s1[0].clone(),
+                dW1.reshape(C1, cin, 1), zeros(C1), s1[1].clone(), s1[0].clone(),
                 dW2.unsqueeze(-1), zeros(C2), s2[1].clone(), s2[0].clone(),
                 dW3.unsqueeze(-1), db3,
                 dW4.unsqueeze(-1), zeros(2 * E), s4[1].clone(), s4[0].clone(),

@@ -442,24 +442,24 @@ def morton_order(centers, resolution=1024, want_codes=False):
 
 
 def apf_group(x, fps_idx, knn_idx, order, want_f32=False, want_x0=True, want_center=True):
-    """Group.forward after the index ops (reference src/models/apf.py:70-110).  Returns (nb_f32 | None, x0_bf16 | None,
-    center | None), rows in Morton order."""
+    """Group.forward after the index ops (reference src/models/apf.py:70-110), x (B,N,C) with C = 3 or 4 (xyz + height).
+    Returns (nb_f32 (B,G,gs,2C) | None, x0_bf16 | None, center (B,G,3) | None), rows in Morton order."""
     _chk(x, 'x', torch.float32, 3)
     _chk(fps_idx, 'fps_idx', torch.int64, 2)
     _chk(knn_idx, 'knn_idx', torch.int32, 3)
     _chk(order, 'order', torch.int32, 2)
     B, N, C = x.shape
-    if C != 3:
-        raise RuntimeError(f'apf_group: built for in_channels=3 (xyz only), got {C} channels')
+    if C not in (3, 4):
+        raise RuntimeError(f'apf_group: built for in_channels 3 (xyz) and 4 (xyz + height), got {C} channels')
     G, gs = knn_idx.shape[1], knn_idx.shape[2]
     if fps_idx.shape != (B, G) or order.shape != (B, G) or knn_idx.shape[0] != B:
         raise RuntimeError('apf_group: index shapes do not match')
     dev = x.device
-    nb = torch.empty(B, G, gs, 6, dtype=torch.float32, device=dev) if want_f32 else None
+    nb = torch.empty(B, G, gs, 2 * C, dtype=torch.float32, device=dev) if want_f32 else None
     x0 = torch.empty(B * G * gs, 64, dtype=torch.bfloat16, device=dev) if want_x0 else None
     cen = torch.empty(B, G, 3, dtype=torch.float32, device=dev) if want_center else None
-    L.call('p4p_apf_group', L.ptr(x), L.ptr(fps_idx), L.ptr(knn_idx), L.ptr(order), L.ptr(nb), L.ptr(x0), L.ptr(cen), B, N, G,
-           gs, _stream())
+    L.call('p4p_apf_group', L.ptr(x), L.ptr(fps_idx), L.ptr(knn_idx), L.ptr(order), L.ptr(nb), L.ptr(x0), L.ptr(cen), B, N, C,
+           G, gs, _stream())
     return nb, x0, cen
 
 

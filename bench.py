@@ -31,11 +31,12 @@ def flop_per_cloud(points, D, L, k=16):
     return 3.0 * (S * k * 920576.0 + L * (24.0 * T * D * D + 4.0 * T * T * D))
 
 
-def apf_flop_per_cloud(G=196, gs=32, E=768, L=12, bottleneck=64):
+def apf_flop_per_cloud(G=196, gs=32, E=768, L=12, bottleneck=64, cin=8):
     """fwd+bwd algorithmic FLOPs per cloud of the APF path (BASELINE.json configs[3]).  Encoder as the reference computes
-    it (src/models/apf.py:129-143: every point meets the full 2E x 2E layer), trainable => 3x forward; transformer with
+    it (src/models/apf.py:129-143: every point meets the full 2E x 2E layer; cin = 8 input channels = the shipped
+    in_channels=4 with the height column, train_apf.py:5), trainable => 3x forward; transformer with
     T = G tokens and the bottleneck adapter, frozen (apf.py:335-346) => forward + input gradient = 2x forward."""
-    enc = G * gs * 2.0 * (6 * 256 + 256 * 512 + 512 * E + 2 * E * 2 * E + 2 * E * E)
+    enc = G * gs * 2.0 * (cin * 256 + 256 * 512 + 512 * E + 2 * E * 2 * E + 2 * E * E)
     vit = L * (24.0 * G * E * E + 4.0 * G * G * E + 4.0 * G * E * bottleneck)
     return 3.0 * enc + 2.0 * vit
 
@@ -130,7 +131,8 @@ class ApfStepper:
         from p4p_amd.optim import FusedAdamW
         torch.manual_seed(1234)
         with contextlib.redirect_stdout(sys.stderr):
-            self.model = p4p_amd.AdaptPointFormer(num_classes=args.classes, vit_name=args.vit, pretrained=False).to(device)
+            self.model = p4p_amd.AdaptPointFormer(num_classes=args.classes, vit_name=args.vit, pretrained=False,
+                                                  in_channels=4).to(device)     # reference train_apf.py:5: xyz + height
         self.model.train()
         broadcast_parameters(self.model)
         self.reducer = GradReducer([[p for p in self.model.parameters() if p.requires_grad]]) if distributed else None
@@ -303,11 +305,12 @@ def cpu_baseline_apf(args, budget_s=25.0):
     torch.set_num_threads(cores)
     log(f'cpu_baseline: {cores} threads')
     torch.manual_seed(0)
-    model = A.AdaptPointFormer(num_classes=args.classes, embedding_dim=D, depth=L, num_heads=H)
+    model = A.AdaptPointFormer(num_classes=args.classes, embedding_dim=D, depth=L, num_heads=H, in_channels=4)
     model.train()
     opt = torch.optim.AdamW(model.parameters(), lr=5e-4, weight_decay=5e-2)
     B = 4
     pts, labels, start = synthetic_batch(B, args.points, args.classes, 99, 'cpu')
+    pts = torch.cat([pts, pts[:, :, 1:2] - pts[:, :, 1:2].min(dim=1, keepdim=True).values], dim=-1)
 
     def one():
         opt.zero_grad()
@@ -437,6 +440,9 @@ def main():
 
     stepper = (ApfStepper if apf else Stepper)(args, device, distributed)
     batch = synthetic_batch(args.batch, args.points, args.classes, 1234 + rank, device)
+    if apf:      # the height column of center_and_normalize_point_cloud (src/data/augment.py:247-248): y - min y per cloud
+        xyz = batch[0]
+        batch = (torch.cat([xyz, xyz[:, :, 1:2] - xyz[:, :, 1:2].min(dim=1, keepdim=True).values], dim=-1).contiguous(),) + batch[1:]
 
     def fence():
         if distributed:
@@ -520,7 +526,7 @@ def main():
             out['allreduce_exposed_ms'] = ar_wait
         if apf:
             out['metric'] = f'point-clouds/sec fwd+bwd (train step), APF adapter path N={args.points} {fam} frozen'
-            out['config']['workload'] = (f'AdaptPointFormer {args.vit} (D={vd}, {vl} frozen blocks + adapters), 196 groups of 32, '
+            out['config']['workload'] = (f'AdaptPointFormer {args.vit} (D={vd}, {vl} frozen blocks + adapters), in_channels=4 (xyz + height), 196 groups of 32, '
                                          f'N={args.points}, {args.classes} classes, batch {args.batch}/GPU; step = zero_grad+fwd+'
                                          f'CE(ls 0.3)+bwd{"+RCCL all-reduce" if distributed else ""}+AdamW(fused), train-mode '
                                          'DropPath/dropout; FLOP model: encoder 3x fwd as the reference computes it, frozen '

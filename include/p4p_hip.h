@@ -194,11 +194,13 @@ int p4p_adamw_step(const void* tensors, const void* chunks, int nchunks, const f
 /* MortonEncoder.points_to_morton (src/models/apf_utils.py:67-104): order[b][r] = index of the centre with the r-th smallest
    30-bit Morton code (equal codes: lowest index first); codes (may be NULL) [B,G] int32.  centers [B,G,3] f32, G <= 4096. */
 int p4p_morton_order_f32(const float* centers, int32_t* order, int32_t* codes, int B, int G, int resolution, void* stream);
-/* Group.forward after the index ops (src/models/apf.py:70-110): x [B,N,3] f32, fps_idx [B,G] i64, knn_idx [B,G,gs] i32,
-   order [B,G] i32.  Outputs, each may be NULL: nb_f32 [B,G,gs,6] = [x[nbr]-x[centre], x[centre]], x0_bf16 [B*G*gs,64] the
-   hi/lo-split bf16 operand of the first 1x1 conv (layout in csrc/apf.hip), center [B,G,3]; all in Morton order. */
+/* Group.forward after the index ops (src/models/apf.py:70-110): x [B,N,C] f32 with C = 3 (xyz) or 4 (xyz + height: the
+   reference's shipped configuration, train_apf.py:5,29), fps_idx [B,G] i64, knn_idx [B,G,gs] i32, order [B,G] i32.
+   Outputs, each may be NULL: nb_f32 [B,G,gs,2C] = [x[nbr]-x[centre], x[centre]] (apf.py:83-95), x0_bf16 [B*G*gs,64] the
+   hi/lo-split bf16 operand of the first 1x1 conv ([hi (2C) | lo (2C) | hi (2C) | 0], csrc/apf.hip), center [B,G,3]
+   (the xyz of the group centres); all in Morton order. */
 int p4p_apf_group(const float* x, const int64_t* fps_idx, const int32_t* knn_idx, const int32_t* order, float* nb_f32,
-                  void* x0_bf16, float* center, int B, int N, int G, int gs, void* stream);
+                  void* x0_bf16, float* center, int B, int N, int C, int G, int gs, void* stream);
 /* torch.max over the points of a group (src/models/apf.py:160,167): H [G*k,C] bf16 -> tok [G,C] (+ bias[c] if given) as f32
    and/or bf16 (either may be NULL), arg [G,C] u8 (may be NULL) = first maximum.  bwd: dH [G*k,C] bf16 = scatter of
    dtok [G,C] (f32 or bf16) to the arg-max rows; accumulate != 0 adds into dH instead of overwriting it. */

@@ -21,6 +21,35 @@ def _bn_train(h, gamma, beta, eps):
     return mean, var, gamma / torch.sqrt(var + eps), beta - mean * gamma / torch.sqrt(var + eps)
 
 
+LINK_LIMITS = {'bf16': 0.05,     # ulps beyond a correct rounding (after the fp32 summation slack, link_stats)
+               'att': 0.6,       # units of max(ulp, 2^-8 rms): half an output ulp + the P roundings inside the kernel (measured 0.51)
+               'f32': 3e-5,      # relative to the tensor's rms
+               'exact': 0.0}
+NORTH_STAR_TOL = 1e-3            # BASELINE.json north_star: "logits within 1e-3"
+
+
+def assert_links(oracle, cap, pts, idx_fps, idx_knn, logits, training=False, grad=False):
+    """Runs the statement link by link against a capture of the pipeline's forward (functional._CAPTURE) and asserts
+    every hand-off (LINK_LIMITS) and the logits (NORTH_STAR_TOL).  Returns (stated logits -- a function of the pipeline's
+    own tensors carrying the statement's autograd graph --, worst value per link)."""
+    tape = Tape(cap)
+    with torch.set_grad_enabled(grad):
+        stated = pix4point_emulated(oracle, pts, idx_fps, idx_knn, training=training, tape=tape)
+    bad, worst = [], {}
+    for name, got, want, kind in tape.links:
+        v = link_stats(got, want, kind)
+        worst[name] = v
+        if not v <= LINK_LIMITS[kind]:
+            bad.append((name, kind, v))
+    err = float((logits.detach() - stated.detach()).abs().max())
+    worst['logits'] = err
+    if not err <= NORTH_STAR_TOL:
+        bad.append(('logits', 'abs', err))
+    assert not bad, bad
+    assert len(tape.links) == 7 + 3 + 1 + 7 * len(cap['blocks']) + 1         # tokenizer, streams, xin, 7 per block, final norm
+    return stated, worst
+
+
 class Tape:
     """How the statements below hand a tensor from one stage to the next.
 

@@ -54,7 +54,16 @@ def test_cpu_tensors_are_rejected_not_silently_computed():
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         PA.MortonEncoder.points_to_morton(torch.zeros(2, 16, 3))
     with pytest.raises(NotImplementedError):
-        PA.Encoder(768, 8)
+        PA.Encoder(768, 10)                     # 6 (xyz) and 8 (xyz + height, the reference's shipped configuration) are built
+
+
+def test_reference_shipped_configuration_with_height_channel():
+    """train_apf.py:5,29 of the reference: in_channels=4 (xyz + height) -> 8-channel groups (apf.py:293)."""
+    o, m = _pair(in_channels=4)
+    so, sm = o.state_dict(), m.state_dict()
+    assert list(so.keys()) == list(sm.keys()) and all(so[k].shape == sm[k].shape for k in so)
+    assert sm['point_encoder.encoder.first_conv.0.weight'].shape == (256, 8, 1)
+    assert m.load_state_dict(A.seeded_state_dict(o, seed=1), strict=True)
 
 
 def test_cosine_warmup_schedule():
@@ -75,5 +84,7 @@ def test_bench_flop_model():
     # ~8.13 MFLOP per position x 196*32 positions ~ 51 GF forward per cloud
     enc_fwd = 196 * 32 * 2.0 * (6 * 256 + 256 * 512 + 512 * 768 + 1536 * 1536 + 1536 * 768)
     assert 50.5e9 < enc_fwd < 51.5e9
-    assert bench.apf_flop_per_cloud() == pytest.approx(3 * enc_fwd + 2 * 12 * (24 * 196 * 768 ** 2 + 4 * 196 ** 2 * 768
+    assert bench.apf_flop_per_cloud(cin=6) == pytest.approx(3 * enc_fwd + 2 * 12 * (24 * 196 * 768 ** 2 + 4 * 196 ** 2 * 768
                                                                                + 4 * 196 * 768 * 64))
+    # the shipped configuration adds two input channels to the first layer: +2 * 256 MACs per point
+    assert bench.apf_flop_per_cloud() - bench.apf_flop_per_cloud(cin=6) == pytest.approx(3 * 196 * 32 * 2.0 * 2 * 256)

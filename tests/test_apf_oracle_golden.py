@@ -121,3 +121,59 @@ def test_full_model_restatement_fixture_and_freeze(golden_dir):
     train = {n.split('.')[0] for n, p in m.named_parameters() if p.requires_grad}
     assert train == {'head', 'encoder_norm', 'point_encoder'}
     assert not any(p.requires_grad for p in m.blocks.parameters())
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's shipped configuration: in_channels = 4 (xyz + height), 8-channel groups   (tests/golden/make_golden_apf_height.py)
+# ---------------------------------------------------------------------------------------------
+def _lexsorted_c(nb):
+    key = np.lexsort([nb[..., c] for c in range(nb.shape[-1] - 1, -1, -1)], axis=-1)
+    return np.take_along_axis(nb, key[..., None], axis=2)
+
+
+@pytest.mark.parametrize('tag', ['n512g64', 'n2048g196'])
+def test_group_with_height_channel_matches_reference(golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, 'apf_height.npz'))
+    B, N, G, gs = (int(v) for v in z[f'group_{tag}_meta'])
+    x = torch.from_numpy(z[f'group_{tag}_x'])
+    start = torch.from_numpy(z[f'group_{tag}_start'])
+    nb, cen = A.Group(G, gs)(x, x[:, :, :3], start)
+    assert nb.shape == (B, G, gs, 8)
+    assert np.array_equal(cen.numpy(), z[f'group_{tag}_center'])
+    xyz = x[:, :, :3].contiguous()
+    order = A.points_to_morton(A.index_points(xyz, A.furthest_point_sample(xyz, G, start))).numpy()
+    clear = np.take_along_axis(z[f'group_{tag}_min_gap'], order, 1) > 2e-6
+    assert clear.mean() > 0.9
+    assert np.array_equal(_lexsorted_c(nb.numpy())[clear], z[f'group_{tag}_neigh_sorted'][clear])
+
+
+@pytest.mark.parametrize('tag', ['ec128', 'ec768'])
+def test_encoder_8_channels_matches_reference(golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, 'apf_height.npz'))
+    B, G, gs, ec = (int(v) for v in z[f'enc_{tag}_meta'])
+    m = A.Encoder(ec, 8)
+    m.load_state_dict(A.seeded_state_dict(m, seed=1400 + ec))
+    x = torch.from_numpy(z[f'enc_{tag}_x'])
+    m.eval()
+    with torch.no_grad():
+        assert np.allclose(m(x).numpy(), z[f'enc_{tag}_eval_tokens'], rtol=1e-5, atol=1e-5)
+    m.train()
+    tok = m(x)
+    assert np.allclose(tok.detach().numpy(), z[f'enc_{tag}_train_tokens'], rtol=1e-5, atol=1e-5)
+    (tok * torch.from_numpy(z[f'enc_{tag}_train_gradw'])).sum().backward()
+    close = lambda a, b: np.allclose(a, b, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(b).max())))
+    assert close(m.first_conv[0].weight.grad.numpy().reshape(256, 8), z[f'enc_{tag}_g_conv0_w'])
+    assert close(m.first_conv[1].weight.grad.numpy(), z[f'enc_{tag}_g_bn1_w'])
+    assert close(m.second_conv[3].bias.grad.numpy(), z[f'enc_{tag}_g_sconv3_b'])
+
+
+def test_pointnet_with_height_channel_matches_reference(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'apf_height.npz'))
+    B, N, G, gs, ec = (int(v) for v in z['pointnet_meta'])
+    pn = A.PointNet(ec, G, gs, 8)
+    pn.load_state_dict(A.seeded_state_dict(pn, seed=1500))
+    pn.eval()
+    with torch.no_grad():
+        tok = pn(torch.from_numpy(z['pointnet_x']), torch.from_numpy(z['pointnet_start'])).numpy()
+    # a group whose neighbour set differs on a near-tie (gap < 2e-6) would move one token; none does on this fixture
+    assert np.allclose(tok, z['pointnet_tokens'], rtol=1e-4, atol=1e-4)

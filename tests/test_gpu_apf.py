@@ -388,7 +388,19 @@ def test_full_model_train_step_gradients_vs_oracle():
     labels = torch.arange(B) % 15
     lo = torch.nn.functional.cross_entropy(o(pts, start), labels, label_smoothing=0.3)
     lo.backward()
-    lg = torch.nn.functional.cross_entropy(m(pts.to(DEV), start.to(DEV)), labels.to(DEV), label_smoothing=0.3)
+    tokens = {}
+
+    def keep_tokens(mod, inp, out):
+        out.retain_grad()
+        tokens['t'] = out
+
+    hook = m.point_encoder.register_forward_hook(keep_tokens)
+    FA._CAPTURE = {}
+    try:
+        lg = torch.nn.functional.cross_entropy(m(pts.to(DEV), start.to(DEV)), labels.to(DEV), label_smoothing=0.3)
+    finally:
+        gates, FA._CAPTURE = FA._CAPTURE, None
+        hook.remove()
     lg.backward()
     assert abs(float(lg.detach()) - float(lo.detach())) < 5e-3 * abs(float(lo.detach()))
     go = dict(o.named_parameters())
@@ -406,7 +418,18 @@ def test_full_model_train_step_gradients_vs_oracle():
     assert len(head) == 12 and len(enc) == 12
     assert max(head.values()) < 8e-2, head                      # head + encoder_norm: smooth
     vals = sorted(enc.values())
-    assert vals[len(vals) // 2] < 0.3 and vals[-1] < 0.4, enc
+    assert vals[len(vals) // 2] < 0.3 and vals[-1] < 0.4, enc   # against the fp32 oracle: its own gates (see the docstring)
+    # THE tight check: the same encoder gradients against the statement that takes the kernels' ReLU / arg-max decisions
+    # (tests/emulate.py) and the model's OWN upstream gradient d(loss)/d(tokens) -- arithmetic only, every layer's scale
+    G, gs = m.point_encoder.group.num_group, m.point_encoder.group.group_size
+    nb, _ = m.point_encoder.group(pts.to(DEV), pts.to(DEV), start.to(DEV))
+    params = {n: p.detach().clone().requires_grad_(True) for n, p in m.point_encoder.encoder.named_parameters()}
+    te = apf_encoder_emulated(nb.reshape(B * G * gs, -1), params, B * G, gs, gates=gates)
+    assert rel_l2(tokens['t'].reshape(B * G, -1), te) < 6e-3
+    te.backward(tokens['t'].grad.reshape(B * G, -1))
+    tight = {n: rel_l2(p.grad, params[n].grad) for n, p in m.point_encoder.encoder.named_parameters()
+             if not n.endswith(zero)}
+    assert len(tight) == 12 and max(tight.values()) < 3e-2, tight
 
 
 def test_full_model_reference_shape_train_step_runs():
@@ -422,3 +445,98 @@ def test_full_model_reference_shape_train_step_runs():
     assert torch.isfinite(loss)
     assert not torch.equal(before, m.point_encoder.encoder.second_conv[3].weight)
     assert torch.equal(frozen, m.blocks[3].mlp.fc1.weight)
+
+
+# --------------------------------------------------------------------------------------------- in_channels = 4 (xyz + height)
+# the reference's shipped configuration (train_apf.py:5,29); fixtures: tests/golden/make_golden_apf_height.py
+def _lexsorted_c(nb):
+    key = np.lexsort([nb[..., c] for c in range(nb.shape[-1] - 1, -1, -1)], axis=-1)
+    return np.take_along_axis(nb, key[..., None], axis=2)
+
+
+@pytest.mark.parametrize('tag', ['n512g64', 'n2048g196'])
+def test_group_with_height_channel_vs_reference_fixture(golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, 'apf_height.npz'))
+    B, N, G, gs = (int(v) for v in z[f'group_{tag}_meta'])
+    x = torch.from_numpy(z[f'group_{tag}_x']).to(DEV)
+    start = torch.from_numpy(z[f'group_{tag}_start']).to(DEV)
+    grp = PA.Group(G, gs)
+    nb, cen = grp(x, x[:, :, :3], start)
+    assert nb.shape == (B, G, gs, 8) and cen.shape == (B, G, 3)
+    assert np.array_equal(cen.cpu().numpy(), z[f'group_{tag}_center']), 'centres (FPS + Morton order) must be bit-exact'
+    nb_o, cen_o = A.Group(G, gs)(x.cpu(), x.cpu()[:, :, :3], start.cpu())
+    assert torch.equal(nb.cpu(), nb_o) and torch.equal(cen.cpu(), cen_o)
+    fps_idx, knn_idx, order = grp.indices(x[:, :, :3], start)
+    clear = np.take_along_axis(z[f'group_{tag}_min_gap'], order.cpu().numpy().astype(np.int64), 1) > 2e-6
+    assert clear.mean() > 0.9
+    assert np.array_equal(_lexsorted_c(nb.cpu().numpy())[clear], z[f'group_{tag}_neigh_sorted'][clear])
+    _, x0, _ = ops.apf_group(x, fps_idx, knn_idx, order)
+    rec = (x0[:, 0:8].float() + x0[:, 8:16].float()).view(B, G, gs, 8)
+    assert float((rec - nb).abs().max()) < 1e-4 and torch.equal(x0[:, 0:8], x0[:, 16:24]) and not x0[:, 24:].any()
+
+
+@pytest.mark.parametrize('tag', ['ec128', 'ec768'])
+def test_encoder_8_channels_against_reference_fixture(golden_dir, tag):
+    z = np.load(os.path.join(golden_dir, 'apf_height.npz'))
+    B, G, gs, ec = (int(v) for v in z[f'enc_{tag}_meta'])
+    m = PA.Encoder(ec, 8)
+    m.load_state_dict(A.seeded_state_dict(A.Encoder(ec, 8), seed=1400 + ec))
+    m = m.to(DEV)
+    x = torch.from_numpy(z[f'enc_{tag}_x']).to(DEV)
+    m.eval()
+    with torch.no_grad():
+        assert rel_l2(m(x), torch.from_numpy(z[f'enc_{tag}_eval_tokens'])) < 1e-2
+    m.train()
+    FA._CAPTURE = {}
+    try:
+        tok = m(x)
+    finally:
+        gates, FA._CAPTURE = FA._CAPTURE, None
+    assert rel_l2(tok, torch.from_numpy(z[f'enc_{tag}_train_tokens'])) < 1e-2
+    w = torch.from_numpy(z[f'enc_{tag}_train_gradw']).to(DEV)
+    (tok * w).sum().backward()
+    # first layer: fp32-class through the hi/lo split (8 channels x 3 = 24 of the 64 padded K columns)
+    run = np.stack([m.first_conv[1].running_mean.cpu().numpy(), m.first_conv[1].running_var.cpu().numpy()])
+    np.testing.assert_allclose(run, z[f'enc_{tag}_bn1_running'], rtol=1e-4, atol=1e-6)
+    assert rel_l2(m.second_conv[3].bias.grad, torch.from_numpy(z[f'enc_{tag}_g_sconv3_b'])) < 1e-5     # = column sums of w
+    # every gradient against the gate-matched statement (arithmetic only) ...
+    params = {n: p.detach().clone().requires_grad_(True) for n, p in m.named_parameters()}
+    te = apf_encoder_emulated(x.reshape(B * G * gs, 8), params, B * G, gs, gates=gates)
+    (te * w.view(B * G, ec)).sum().backward()
+    zero = ('first_conv.0.bias', 'first_conv.3.bias', 'second_conv.0.bias', 'first_conv.6.bias')
+    errs = {n: rel_l2(p.grad, params[n].grad) for n, p in m.named_parameters() if n not in zero}
+    assert max(errs.values()) < 2e-2, errs
+    assert m.first_conv[0].weight.grad.shape == (256, 8, 1)
+    # ... and the first layer against the reference fixture (fp32 gates: bounded as in the 6-channel test)
+    assert rel_l2(m.first_conv[0].weight.grad.reshape(256, 8), torch.from_numpy(z[f'enc_{tag}_g_conv0_w'])) < 0.25
+
+
+def test_pointnet_with_height_channel_vs_reference_fixture(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'apf_height.npz'))
+    B, N, G, gs, ec = (int(v) for v in z['pointnet_meta'])
+    pn = PA.PointNet(ec, G, gs, 8)
+    pn.load_state_dict(A.seeded_state_dict(A.PointNet(ec, G, gs, 8), seed=1500))
+    pn = pn.to(DEV).eval()
+    with torch.no_grad():
+        tok = pn(torch.from_numpy(z['pointnet_x']).to(DEV), torch.from_numpy(z['pointnet_start']).to(DEV))
+    assert tok.shape == (B, G, ec)
+    assert rel_l2(tok, torch.from_numpy(z['pointnet_tokens'])) < 1e-2
+    with pytest.raises(RuntimeError, match='input channels'):
+        pn(torch.zeros(B, N, 3, device=DEV))
+
+
+def test_full_model_with_height_channel_vs_oracle_and_train_step():
+    o, m = _model_pair(41, in_channels=4, dropout_rate=0.0, dropout_path_rate=0.0)
+    B, N = 6, 512
+    xyz = A.synthetic_clouds(B, N, seed=42)
+    x = torch.cat([xyz, xyz[:, :, 1:2] - xyz[:, :, 1:2].min(dim=1, keepdim=True).values], dim=-1)     # augment.py:247-248
+    start = torch.arange(B) * 3
+    o.eval(), m.eval()
+    with torch.no_grad():
+        want, got = o(x, start), m(x.to(DEV), start.to(DEV)).cpu()
+    assert float((got - want).abs().max()) < 1e-2 * max(1.0, float(want.abs().max()))
+    m.train()
+    loss = torch.nn.functional.cross_entropy(m(x.to(DEV), start.to(DEV)), torch.arange(B, device=DEV) % 15, label_smoothing=0.3)
+    loss.backward()
+    g = m.point_encoder.encoder.first_conv[0].weight.grad
+    assert g.shape == (256, 8, 1) and bool(torch.isfinite(g).all()) and float(g[:, 3].abs().sum()) > 0     # the height column learns

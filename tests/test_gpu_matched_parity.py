@@ -26,7 +26,7 @@ from tests import emulate as E                    # noqa: E402
 from tests.test_gpu_model import build_pair, rel_l2, _no_dropout      # noqa: E402
 
 DEV = 'cuda'
-NORTH_STAR_TOL = 1e-3
+NORTH_STAR_TOL = E.NORTH_STAR_TOL
 
 
 def _indices(pts, start, k=16):
@@ -57,31 +57,7 @@ def _captured_forward(model, pts, start, training):
     return logits, cap
 
 
-LINK_LIMITS = {'bf16': 0.05,     # ulps beyond a correct rounding (after the fp32 summation slack, emulate.link_stats)
-               'att': 0.6,       # units of max(ulp, 2^-8 rms): half an output ulp + the P roundings inside the kernel (measured 0.51)
-               'f32': 3e-5,      # relative to the tensor's rms
-               'exact': 0.0}
-
-
-def _check_links(oracle, cap, pts, idx, nb, logits, training, grad=False):
-    """Runs the statement link by link against the capture; returns (stated logits [a function of the pipeline's own
-    tensors, with the statement's autograd graph], worst value per link)."""
-    tape = E.Tape(cap)
-    with torch.set_grad_enabled(grad):
-        stated = E.pix4point_emulated(oracle, pts, idx, nb, training=training, tape=tape)
-    bad, worst = [], {}
-    for name, got, want, kind in tape.links:
-        v = E.link_stats(got, want, kind)
-        worst[name] = v
-        if not v <= LINK_LIMITS[kind]:
-            bad.append((name, kind, v))
-    err = float((logits.detach() - stated.detach()).abs().max())
-    worst['logits'] = err
-    if not err <= NORTH_STAR_TOL:
-        bad.append(('logits', 'abs', err))
-    assert not bad, bad
-    assert len(tape.links) == 7 + 3 + 1 + 7 * len(cap['blocks']) + 1         # tokenizer, streams, xin, 7 per block, final norm
-    return stated, worst
+_check_links = E.assert_links          # every hand-off within LINK_LIMITS, logits within NORTH_STAR_TOL (tests/emulate.py)
 
 
 @pytest.mark.parametrize('D,L,H,B,N', CONFIGS)
@@ -113,7 +89,7 @@ def test_train_step_link_by_link_loss_and_gradients(D, L, H, B, N, gmax_tol, gme
     stated, _ = _check_links(oracle, cap, pts.to(DEV), idx.to(DEV), nb.to(DEV), logits, True, grad=True)
     lk = torch.nn.functional.cross_entropy(logits, labels)
     le = torch.nn.functional.cross_entropy(stated, labels)
-    assert abs(float(lk) - float(le)) <= NORTH_STAR_TOL, (float(lk), float(le))
+    assert abs(float(lk.detach()) - float(le.detach())) <= NORTH_STAR_TOL, (float(lk.detach()), float(le.detach()))
     # gradients: the statement's autograd, evaluated AT the pipeline's forward tensors (identical ReLU masks, arg-max picks
     # and softmax numerators), against the backward kernels; what differs is the bf16 rounding of the backward operands
     lk.backward()

@@ -60,19 +60,24 @@ def test_trainer_rejects_cpu_device(tmp_path):
         p4p_amd.Pix4PointTrainer(mc, dc, tc, device='cpu', output_dir=str(tmp_path / 'x'))
 
 
-def test_apf_trainer_end_to_end(tmp_path):
+@pytest.mark.parametrize('height', [False, True])
+def test_apf_trainer_end_to_end(tmp_path, height):
     """reference src/train/apf_trainer.py: CSV header with the learning-rate column, model_best.pt, the checkpoint dict,
-    frozen blocks untouched by training, trainable tokenizer / head moving."""
-    mc = {'num_classes': 8, 'in_channels': 3, 'vit_name': 'vit_custom_d192_l2_h3', 'pretrained': False,
+    frozen blocks untouched by training, trainable tokenizer / head moving.  height=True is the reference's shipped
+    configuration (train_apf.py:5,29: in_channels=4, use_height=True)."""
+    mc = {'num_classes': 8, 'in_channels': 4 if height else 3, 'vit_name': 'vit_custom_d192_l2_h3', 'pretrained': False,
           'embedding_dim': 192, 'npoint': 32, 'nsample': 16, 'dropout_rate': 0.1, 'drop_path_rate': 0.1, 'depth': 2,
           'num_heads': 3}
     dc = {'root_dir': 'synthetic', 'variant': 'main_split', 'augmentation': 'none', 'train_num_points': 256,
-          'test_num_points': 128, 'num_samples': 64}
+          'test_num_points': 128, 'num_samples': 64, 'use_height': height}
     tc = {'batch_size': 16, 'epochs': 3, 'save_interval': 1, 'label_smoothing': 0.3, 'learning_rate': 2e-3,
           'weight_decay': 5e-2, 'warmup_epochs': 1, 'warmup_lr_init': 1e-3}
     out = str(tmp_path / 'apf')
     torch.manual_seed(0)
     tr = p4p_amd.APFTrainer(mc, dc, tc, device='cuda', output_dir=out)
+    assert tr.model.point_encoder.encoder.first_conv[0].weight.shape == (256, 8 if height else 6, 1)
+    with pytest.raises(ValueError, match='use_height'):
+        p4p_amd.APFTrainer(dict(mc, in_channels=3 if height else 4), dc, tc, device='cuda', output_dir=out + '_bad')
     frozen0 = tr.model.blocks[1].mlp.fc1.weight.detach().clone()
     enc0 = tr.model.point_encoder.encoder.second_conv[3].weight.detach().clone()
     tr.train()

@@ -11,14 +11,14 @@ from p4p_amd.apf_trainer import APFTrainer
 
 model_config = {
     'num_classes': 15,
-    'in_channels': 3,
+    'in_channels': 4,              # xyz + height (reference train_apf.py:5)
     'vit_name': 'vit_base_patch16_224',
     'pretrained': False,           # True needs a local state dict in $P4P_PRETRAINED_DIR (no downloads)
     'embedding_dim': 768,
     'npoint': 196,
     'nsample': 32,
     'dropout_rate': 0.1,
-    'drop_path_rate': 0.1,
+    'dropout_path_rate': 0.1,      # the reference's key (train_apf.py:12); its trainer reads 'drop_path_rate' (apf_trainer.py:79)
 }
 
 dataset_config = {
@@ -28,6 +28,7 @@ dataset_config = {
     'train_num_points': 2048,
     'test_num_points': 1024,
     'num_samples': 1024,
+    'use_height': True,            # reference train_apf.py:29
 }
 
 train_config = {
