@@ -135,14 +135,32 @@ __device__ __forceinline__ void wave_colsum(const f32x4 (&x)[4], bool valid, flo
     dst[16 * (i >> 2) + 4 * g + (i & 3)] = tot;
 }
 
-__device__ __forceinline__ float xor_lanes_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16));
-    return fmaxf(v, __shfl_xor(v, 32));
+// all-to-all over the four lanes {i, i+16, i+32, i+48} that share a query (or key) column of an MFMA accumulator: two
+// half-exchanges (v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second; v_permlane16_swap: odd
+// 16-lane rows of the first <-> even rows of the second), VALU only -- no LDS round trip as ds_bpermute / __shfl_xor.
+// INLINE ASM on purpose: with __builtin_amdgcn_permlane{16,32}_swap this hipcc (ROCm 7.2) folds the second result into
+// the first when both operands are the same value (`v_permlane32_swap v1, v2; v_add v1, v1, v1`: found as a wrong softmax);
+// the s_nop 1 covers the "VALU write -> v_permlane read" hazard that hipcc does not pad inside a string.
+__device__ __forceinline__ void lane_swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void lane_swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float quad_rows_max(float v) {
+    float a = v, b = v;
+    lane_swap32(a, b);
+    a = b = __builtin_fmaxf(a, b);
+    lane_swap16(a, b);
+    return __builtin_fmaxf(a, b);
 }
-__device__ __forceinline__ float xor_lanes_sum(float v) {
-    v += __shfl_xor(v, 16);
-    return v + __shfl_xor(v, 32);
+__device__ __forceinline__ float quad_rows_sum(float v) {
+    float a = v, b = v;
+    lane_swap32(a, b);
+    a = b = a + b;
+    lane_swap16(a, b);
+    return a + b;
 }
+
+// (the streaming kernels call these once per key tile: as __shfl_xor they were two ds_bpermute round trips each)
+__device__ __forceinline__ float xor_lanes_max(float v) { return quad_rows_max(v); }
+__device__ __forceinline__ float xor_lanes_sum(float v) { return quad_rows_sum(v); }
 
 // ------------------------------------------------------------------------------------------------
 // forward
@@ -990,23 +1008,30 @@ __global__ __launch_bounds__(RES_DKDV_NW * 64, 2) void attn_bwd_dkdv_res_kernel(
             stats[(e >> 6) * 128 + 64 + (e & 63)] = del_b[qq];
         }
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-
     const int nkt16 = (T + 15) >> 4;
     const int w0 = (wave + (bh >> 3)) & (RES_DKDV_NW - 1);
     f32x4 ksum[4], vsum[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) ksum[d] = vsum[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kt = w0; kt < nkt16; kt += RES_DKDV_NW) {
-        const int key = kt * 16 + i;
-        const int kc = key < T ? key : T - 1;
-        bf16x8 kf[2], vf[2];
+    // this wave's key fragments are fetched one tile AHEAD (the first ones while the Q / dO pieces are still in flight):
+    // at two waves per SIMD a load at the head of each tile is ~1 us of exposed latency per tile
+    auto load_kv = [&](int kt, bf16x8 (&kf)[2], bf16x8 (&vf)[2]) {
+        int kc = kt * 16 + i;
+        kc = kc < T ? kc : T - 1;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             kf[ks] = *reinterpret_cast<const bf16x8*>(seq + (size_t)kc * ld + D + h * HD + ks * 32 + g * 8);
             vf[ks] = *reinterpret_cast<const bf16x8*>(seq + (size_t)kc * ld + 2 * D + h * HD + ks * 32 + g * 8);
         }
+    };
+    bf16x8 kf[2], vf[2], kfn[2], vfn[2];
+    load_kv(w0, kf, vf);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+
+    for (int kt = w0; kt < nkt16; kt += RES_DKDV_NW) {
+        const int key = kt * 16 + i;
+        if (kt + RES_DKDV_NW < nkt16) load_kv(kt + RES_DKDV_NW, kfn, vfn);
         f32x4 dk[4], dv[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) dk[d] = dv[d] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1029,6 +1054,8 @@ __global__ __launch_bounds__(RES_DKDV_NW * 64, 2) void attn_bwd_dkdv_res_kernel(
                 }
             }
         }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { kf[ks] = kfn[ks]; vf[ks] = vfn[ks]; }
     }
     if (p.colsum) {
         float* row = p.colsum + ((size_t)b * RES_COLSUM_ROWS + wave) * ld + h * HD;
@@ -1040,6 +1067,8 @@ __global__ __launch_bounds__(RES_DKDV_NW * 64, 2) void attn_bwd_dkdv_res_kernel(
         }
     }
 }
+
+#include "attention_lone.h"
 
 static int check_attn(const char* fn, int B, int T, int H, int D) {
     P4P_CHECK(B >= 1 && T >= 1 && H >= 1, "%s: bad sizes B=%d T=%d H=%d", fn, B, T, H);
@@ -1056,7 +1085,16 @@ extern "C" int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B,
     p.qkv = (const __bf16*)qkv; p.out = (__bf16*)out; p.lse2 = lse2; p.B = B; p.T = T; p.H = H; p.D = D; p.scale = scale;
     const bool prof = p4p_prof_begin(3, 4.0 * B * H * (double)T * T * HD, (hipStream_t)stream);      // bench.py: attention forward
     static const bool no_res = getenv("P4P_ATTN_NO_RES") != nullptr;          // A/B switch (tools/ab_bench.sh)
-    if (T <= RES_ROWS - 31 && T >= 64 && !no_res)
+    static const bool no_lone = getenv("P4P_ATTN_NO_LONE") != nullptr;        // A/B switch
+    if (T % 64 == 1 && T >= 65 && T <= 257 && !no_lone) {                    // 64 n + 1 rows: attention_lone.h
+        const dim3 grid(B * H), block(LONE_NW * 64);
+        switch ((T - 1) / 64) {
+            case 1: hipLaunchKernelGGL(attn_fwd_lone_res_kernel<1>, grid, block, 0, (hipStream_t)stream, p); break;
+            case 2: hipLaunchKernelGGL(attn_fwd_lone_res_kernel<2>, grid, block, 0, (hipStream_t)stream, p); break;
+            case 3: hipLaunchKernelGGL(attn_fwd_lone_res_kernel<3>, grid, block, 0, (hipStream_t)stream, p); break;
+            default: hipLaunchKernelGGL(attn_fwd_lone_res_kernel<4>, grid, block, 0, (hipStream_t)stream, p); break;
+        }
+    } else if (T <= RES_ROWS - 31 && T >= 64 && !no_res)
         hipLaunchKernelGGL(attn_fwd_res_kernel, dim3(B * H), dim3(RES_NW * 64), 0, (hipStream_t)stream, p);
     else {
         // measured at B=256, H=12 (tools/attn_ab.py): T=513: 542 / 499 / 533 us for 1 / 2 / 4 tiles per wave; T=2049: 5398 / 4643 / 4501

@@ -62,3 +62,25 @@ extern "C" int p4p_prof_collect(double* out) {
     g_prof_used = 0;
     return 0;
 }
+
+// ---- CU-masked streams: a stream whose kernels may only occupy the compute units whose bit is set in `mask`
+// (hipExtStreamCreateWithCUMask).  Two such streams with disjoint masks PARTITION the chip: a memory-bound kernel on one
+// and an MFMA-bound kernel on the other then really overlap (two unmasked streams only time-slice whole CUs, because a
+// 512-thread / 256-VGPR workgroup fills a CU).  words = number of 32-bit mask words (8 for 256 CUs).
+extern "C" int p4p_stream_create_cu_mask(const uint32_t* mask, int words, void** out) {
+    P4P_CHECK(mask && out && words >= 1, "p4p_stream_create_cu_mask: bad arguments");
+    hipStream_t st;
+    P4P_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask));
+    *out = (void*)st;
+    return 0;
+}
+extern "C" int p4p_stream_destroy(void* stream) {
+    P4P_HIP(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
+extern "C" int p4p_device_cu_count(void) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+    return n;
+}

@@ -159,6 +159,12 @@ int p4p_embed_stage1_bwd(const float* points, const float* feats, const int32_t*
  * collect(): out[0] = total ms, out[1] = launches, out[2] = algorithmic FLOPs (2MNK; attention 4 B H T^2 64, x2.5 backward). */
 int p4p_prof_enable(int kind);
 int p4p_prof_collect(double* out);
+/* ---- CU-masked streams (hipExtStreamCreateWithCUMask): kernels of such a stream only occupy the compute units whose bit is
+ * set in mask[words]; disjoint masks partition the chip between a memory-bound and an MFMA-bound stream.  The reference has
+ * no counterpart (single stream, src/train/pix4point_trainer.py:153-176). */
+int p4p_stream_create_cu_mask(const uint32_t* mask, int words, void** out_stream);
+int p4p_stream_destroy(void* stream);
+int p4p_device_cu_count(void);
 /* experiment switches (tools/gemm_bench.py): tile configuration overrides, 0 = automatic */
 int p4p_set_gemm_variant(int v);
 int p4p_set_wgrad_wide(int v);

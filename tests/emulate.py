@@ -141,27 +141,78 @@ def _exp2_fma(s, c, m):
     return torch.exp2(smooth + (exact - smooth).detach())
 
 
-def attention_emulated(qkv, B, T, H, round_output=True):
-    """qkv [B*T, 3*H*64] (bf16-valued fp32) -> attention output [B*T, H*64].  Online softmax over 64-key tiles in
-    ascending order (csrc/attention.hip: attn_fwd_tile): running maximum m in the base-2 domain c*s, numerators
-    p = exp2(c*s - m) ROUNDED TO bf16 for the P.V product but summed in fp32 for the denominator, accumulator rescaled by
-    exp2(m_old - m_new) per tile, one division at the end, result rounded to bf16."""
-    hd = 64
-    c = float(torch.tensor(hd ** -0.5, dtype=torch.float32) * torch.tensor(LOG2E, dtype=torch.float32))
-    q, k, v = qkv.view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)          # [B,H,T,hd] each
-    s = q @ k.transpose(-1, -2)                                        # [B,H,T,T] fp32 (exact bf16 products)
-    m = torch.full((B, H, T, 1), float('-inf'), device=qkv.device)
-    lsum = torch.zeros(B, H, T, 1, device=qkv.device)
-    o = torch.zeros(B, H, T, hd, device=qkv.device)
-    for k0 in range(0, T, KEY_TILE):
-        st = s[..., k0:k0 + KEY_TILE]
+def attention_lone_mode(T):
+    """Which arithmetic contract p4p_attention_fwd follows for a sequence of T rows (csrc/attention.hip dispatch):
+    'two_pass' = csrc/attention_lone.h (T = 64 n + 1 <= 257), 'online' = every other shape (attention.hip).
+    (A streaming variant with the last row apart -- the last key as the first step of every query's online softmax, the
+    last query as four chains of block 0 combined through LDS -- was built, verified against its own statement here and
+    measured: 515 vs 490 us at T = 513, 4.30 vs 4.41 ms at T = 2049; not kept)"""
+    return 'two_pass' if (T % 64 == 1 and 65 <= T <= 257) else 'online'
+
+
+def _attention_two_pass(s, v, c):
+    """csrc/attention_lone.h.  s [B,H,T,T] scores, v [B,H,T,hd]; returns the unrounded output [B,H,T,hd].
+    Main query rows (all but the last): exact row maximum over ALL keys, numerators rounded to bf16 for the P.V product
+    AND for the row sum (the sum comes out of the matrix pipe), no rescale.  The last row: the same per 64-key tile (tile
+    0 also holds the last key), the per-tile (max, sum, accumulator) triples combined afterwards."""
+    T = s.shape[-1]
+    TL = T - 1
+    sm = s[:, :, :TL, :]
+    m = (sm.max(-1, keepdim=True).values * c).detach()
+    pr = _r(_exp2_fma(sm, c, m))
+    main = (pr @ v) * (1.0 / pr.sum(-1, keepdim=True))
+    sl = s[:, :, TL:, :]                                              # [B,H,1,T]
+    ms, os_, ls = [], [], []
+    for k0 in range(0, TL, KEY_TILE):
+        keys = list(range(k0, k0 + KEY_TILE)) + ([TL] if k0 == 0 else [])
+        st = sl[..., keys]
+        mt = (st.max(-1, keepdim=True).values * c).detach()
+        pt = _r(_exp2_fma(st, c, mt))
+        ms.append(mt), os_.append(pt @ v[:, :, keys]), ls.append(pt.sum(-1, keepdim=True))
+    M = torch.stack(ms, 0).max(0).values
+    o = sum(torch.exp2(mt - M) * ot for mt, ot in zip(ms, os_))
+    l = sum(torch.exp2(mt - M) * lt for mt, lt in zip(ms, ls))
+    return torch.cat([main, o * (1.0 / l)], dim=2)
+
+
+def _online_chain(s, v, c, key_groups, m=None, lsum=None, o=None):
+    """One online-softmax chain over the given key groups (lists of key indices), attention.hip: attn_fwd_tile: running
+    maximum, numerators rounded to bf16 for P.V but summed in fp32, accumulator rescaled per group.  A group of ONE key
+    whose numerator is exactly 1 reproduces the 'last key first' start of attention_lone.h."""
+    B, H, R, _ = s.shape
+    if m is None:
+        m = torch.full((B, H, R, 1), float('-inf'), device=s.device)
+        lsum = torch.zeros(B, H, R, 1, device=s.device)
+        o = torch.zeros(B, H, R, v.shape[-1], device=s.device)
+    for keys in key_groups:
+        st = s[..., keys]
         mnew = torch.maximum(m, (st.max(-1, keepdim=True).values * c).detach())
         alpha = torch.exp2(m - mnew)
         p = _exp2_fma(st, c, mnew)
         lsum = lsum * alpha + p.sum(-1, keepdim=True)
-        o = o * alpha + _r(p) @ v[:, :, k0:k0 + KEY_TILE]
+        o = o * alpha + _r(p) @ v[:, :, keys]
         m = mnew
-    out = o * (1.0 / lsum)
+    return m, lsum, o
+
+
+def attention_emulated(qkv, B, T, H, round_output=True):
+    """qkv [B*T, 3*H*64] (bf16-valued fp32) -> attention output [B*T, H*64].  Two contracts, chosen as the library
+    chooses its kernel (attention_lone_mode):
+    'online'  (csrc/attention.hip: attn_fwd_tile): online softmax over 64-key tiles in ascending order: running maximum m
+              in the base-2 domain c*s, numerators p = exp2(c*s - m) ROUNDED TO bf16 for the P.V product but summed in fp32
+              for the denominator, accumulator rescaled by exp2(m_old - m_new) per tile, one division at the end;
+    'two_pass' (csrc/attention_lone.h): see _attention_two_pass.
+    The result is rounded to bf16 (round_output=False: the fp32 value in front of that rounding)."""
+    hd = 64
+    c = float(torch.tensor(hd ** -0.5, dtype=torch.float32) * torch.tensor(LOG2E, dtype=torch.float32))
+    q, k, v = qkv.view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)          # [B,H,T,hd] each
+    s = q @ k.transpose(-1, -2)                                        # [B,H,T,T] fp32 (exact bf16 products)
+    mode = attention_lone_mode(T)
+    if mode == 'two_pass':
+        out = _attention_two_pass(s, v, c)
+    else:
+        _, lsum, o = _online_chain(s, v, c, [list(range(k0, min(k0 + KEY_TILE, T))) for k0 in range(0, T, KEY_TILE)])
+        out = o * (1.0 / lsum)
     if round_output:
         out = _r(out)
     return out.permute(0, 2, 1, 3).reshape(B * T, H * hd)

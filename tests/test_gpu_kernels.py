@@ -354,7 +354,7 @@ def _attn_ref(qkv, B, T, H):
 
 
 @pytest.mark.parametrize('B,T,H', [(2, 1, 1), (2, 17, 3), (3, 64, 2), (2, 65, 3), (2, 100, 2), (1, 129, 1), (2, 192, 2),
-                                   (2, 256, 2), (2, 257, 3), (2, 258, 1), (1, 513, 2), (1, 2049, 1),
+                                   (2, 256, 2), (2, 257, 3), (2, 258, 1), (2, 321, 2), (1, 513, 2), (1, 2049, 1),
                                    (2, 2049, 16)])          # BASELINE configs[4]: ViT-L heads at N=8192
 def test_attention_fwd_bwd(B, T, H):
     D = 64 * H
