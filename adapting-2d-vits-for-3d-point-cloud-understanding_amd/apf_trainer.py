@@ -60,16 +60,25 @@ class APFTrainer(Pix4PointTrainer):
         self.reducer = (GradReducer([[p for p in self.model.parameters() if p.requires_grad]])
                         if self.distributed else None)
 
-    # ---- reference :84-146 (ScanObjectNN reader: later-round item, as in trainer.py)
+    # ---- reference :84-146
     def _init_datasets(self) -> None:
         c = self.dataset_config
-        if c.get('root_dir') != 'synthetic':
-            raise NotImplementedError("ScanObjectNN loading is a later-round item (SURVEY.md section 8f-3); "
-                                      "use dataset_config['root_dir']='synthetic'")
-        n = c.get('num_samples', 2048)
-        k = self.model_config['num_classes']
-        self.train_dataset = SyntheticClouds(n, c['train_num_points'], k, seed=1234)
-        self.test_dataset = SyntheticClouds(max(n // 4, 1), c['test_num_points'], k, seed=4321)
+        if c.get('root_dir') != 'synthetic':            # reference :100-141; transforms / height: on the device batch below
+            from .scanobjectnn import ScanObjectNN
+            common = dict(root_dir=c['root_dir'], variant=c['variant'], augmentation=c['augmentation'],
+                          background=c.get('background', False), use_newsplit=c.get('use_newsplit', False), normalize=False,
+                          sampling_method=c.get('sampling_method', 'fps'), use_height=c.get('use_height', False),
+                          fps_seed=c.get('fps_seed'), fps_device=self.device)
+            self.train_dataset = ScanObjectNN(split='training', num_points=c['train_num_points'], **common)
+            self.test_dataset = ScanObjectNN(split='test', num_points=c['test_num_points'], **common)
+            if self.rank == 0:
+                print(f"Dataset loaded: {len(self.train_dataset)} train samples, {len(self.test_dataset)} test samples")
+                print(f"Number of classes: {self.train_dataset.num_classes}")
+        else:
+            n = c.get('num_samples', 2048)
+            k = self.model_config['num_classes']
+            self.train_dataset = SyntheticClouds(n, c['train_num_points'], k, seed=1234)
+            self.test_dataset = SyntheticClouds(max(n // 4, 1), c['test_num_points'], k, seed=4321)
         # the reference's per-cloud numpy transforms (:88-98: scale_point_cloud, center_and_normalize_point_cloud,
         # rotate_point_cloud for training; center_and_normalize_point_cloud for testing) on the device batch
         gen = [None]

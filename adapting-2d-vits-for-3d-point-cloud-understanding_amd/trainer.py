@@ -2,9 +2,9 @@
 ``train()`` / ``load_checkpoint()``, CSV schema and checkpoint dict), running the HIP model, plus what the
 reference lacks for an 8-GPU node: one process per GPU with RCCL gradient all-reduce (ddp.py).
 
-The ScanObjectNN h5 reader and numpy augmentations (src/data/*) are outside this round's scope
-(SURVEY.md section 8f-3); ``dataset_config['root_dir'] == 'synthetic'`` selects ModelNet40-shaped synthetic
-clouds, anything else needs h5py and raises a clear error when it is missing.
+``dataset_config['root_dir'] == 'synthetic'`` selects ModelNet40-shaped synthetic clouds; any other value is a
+ScanObjectNN directory read by p4p_amd.scanobjectnn (the reference's path rules, sampling modes and dataset-level FPS, on
+an .h5 or its .npz conversion).  Normalisation / augmentation run on the device batch (augment.py).
 """
 import csv
 import os
@@ -84,13 +84,20 @@ class Pix4PointTrainer:
             n = c.get('num_samples', 2048)
             self.train_dataset = SyntheticClouds(n, c['num_points'], self.model_config['num_classes'], seed=1234)
             self.test_dataset = SyntheticClouds(max(n // 4, 1), c['num_points'], self.model_config['num_classes'], seed=4321)
-        else:
-            try:
-                import h5py  # noqa: F401
-            except ImportError as e:
-                raise RuntimeError("the ScanObjectNN h5 reader (reference src/data/scanobjectnn.py) needs h5py, which is "
-                                   "not installed; use dataset_config['root_dir']='synthetic'") from e
-            raise NotImplementedError("ScanObjectNN loading is a later-round item (SURVEY.md section 8f-3)")
+        else:       # reference :57-79; normalize / custom augmentation happen on the device batch below, not per sample
+            from .scanobjectnn import ScanObjectNN
+            common = dict(root_dir=c['root_dir'], variant=c['variant'], augmentation=c['augmentation'],
+                          num_points=c['num_points'], normalize=False, sampling_method=c.get('sampling_method', 'all'),
+                          fps_seed=c.get('fps_seed'), fps_device=self.device)
+            if self.rank == 0:
+                print("Loading training dataset...")
+            self.train_dataset = ScanObjectNN(split='training', use_custom_augmentation=c.get('use_custom_augmentation', False),
+                                              **common)
+            if self.rank == 0:
+                print("Loading test dataset...")
+            self.test_dataset = ScanObjectNN(split='test', use_custom_augmentation=False, **common)
+            if self.rank == 0:
+                print(f"Dataset loaded: {len(self.train_dataset)} train samples, {len(self.test_dataset)} test samples")
         assert self.train_dataset.num_classes == self.model_config['num_classes'], \
             "Number of classes in model config must match dataset classes"
         # the reference normalises / augments one cloud at a time in numpy inside ScanObjectNN.__getitem__
