@@ -133,8 +133,10 @@ class APFTrainer(Pix4PointTrainer):
         loss = self.criterion(logits, labels)
         loss.backward()
         if self.reducer is not None:
-            self.reducer.finish()
-        self.optimizer.step()
+            self.reducer.finish(average=False)            # .grad holds SUMS; 1/world is applied inside the fused update
+            self.optimizer.step(grad_scale=self.reducer.grad_scale)
+        else:
+            self.optimizer.step()
         return loss, logits
 
     # ---- reference :205-247: the scheduler is stepped with the epoch index after the test phase

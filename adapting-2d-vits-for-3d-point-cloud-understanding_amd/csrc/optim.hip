@@ -48,8 +48,11 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const P4POptTensor* __r
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// out[0] = clip coefficient, out[1] = total norm
-__global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict__ partial, int n, float max_norm, float* __restrict__ out) {
+// out[0] = gradient factor = grad_scale * clip coefficient, out[1] = total norm of the SCALED gradients.  grad_scale is the
+// data-parallel 1/world (the all-reduce sums; the mean is never written back to the 345-MB gradient buffer).  A NaN norm
+// gives a NaN factor, as torch.nn.utils.clip_grad_norm_ does (clamp(nan) = nan): the blow-up stays visible.
+__global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict__ partial, int n, float max_norm, float grad_scale,
+                                                        float* __restrict__ out) {
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
     __shared__ float red[4];
@@ -57,9 +60,9 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+        const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3])) * grad_scale;
         const float coef = max_norm / (norm + 1e-6f);
-        out[0] = coef < 1.f ? coef : 1.f;
+        out[0] = ((coef < 1.f || coef != coef) ? coef : 1.f) * grad_scale;
         out[1] = norm;
     }
 }
@@ -118,9 +121,11 @@ extern "C" int p4p_grad_sumsq(const void* tensors, const void* chunks, int nchun
     return 0;
 }
 
-extern "C" int p4p_clip_coef(const float* partial, int nchunks, float max_norm, float* coef_and_norm, void* stream) {
-    P4P_CHECK(partial && coef_and_norm && nchunks >= 1 && max_norm > 0.f, "p4p_clip_coef: bad arguments");
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nchunks, max_norm, coef_and_norm);
+extern "C" int p4p_clip_coef(const float* partial, int nchunks, float max_norm, float grad_scale, float* coef_and_norm,
+                             void* stream) {
+    P4P_CHECK(partial && coef_and_norm && nchunks >= 1 && max_norm > 0.f && grad_scale > 0.f, "p4p_clip_coef: bad arguments");
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nchunks, max_norm, grad_scale,
+                       coef_and_norm);
     P4P_LAUNCH_CHECK();
     return 0;
 }

@@ -6,17 +6,22 @@ is the gradient all-reduce.  Design:
 
 * every trainable parameter's ``.grad`` is a VIEW into one flat fp32 buffer, laid out in the order
   gradients become ready: [block L-1 | ... | block 0 | everything else].  No flatten / unflatten copies.
-* ``block_ready`` is called by the encoder's backward (functional._EncoderFn) as soon as one block's
-  twelve gradients exist; it adds them into the views and launches that bucket's all-reduce
-  asynchronously on RCCL's stream, overlapping with the backward of the remaining blocks.
-* ``finish`` (after ``loss.backward()``) reduces the tail bucket, waits for all handles and scales by
-  1/world.  BatchNorm statistics stay per rank (what a per-rank reference run would compute).
+* the encoder's backward (functional._EncoderFn) asks for a block's destination views (``grad_views``) and lets the
+  weight-gradient GEMMs write STRAIGHT into them (the four matrices are 99.9 % of a block's 28 MB); the eight small
+  vectors are copied.  ``block_done`` then launches that bucket's all-reduce asynchronously on RCCL's stream,
+  overlapping with the backward of the remaining blocks.  Nothing is added into the buffer, so only the tail bucket
+  (whose gradients autograd accumulates) is zeroed per step.
+* ``finish`` (after ``loss.backward()``) reduces the tail bucket and waits for all handles.  The buffer then holds SUMS;
+  ``grad_scale`` = 1/world goes to ``FusedAdamW.step(grad_scale=...)``, which folds it into the clip coefficient (no
+  pass over the 345-MB buffer); ``finish(average=True)`` scales in place for a stock optimizer.
+  BatchNorm statistics stay per rank (what a per-rank reference run would compute).
 * parameters that never receive a gradient (timm's unused patch_embed / pos_embed / head, SURVEY.md
   quirk 8) are simply not in any bucket.
 
-xGMI is point-to-point (7 links per GPU): a ViT-B gradient set is 345 MB fp32; per-block buckets of
-28 MB keep each ring step well above the latency floor while leaving 12 collectives in flight behind
-~60 ms of backward compute.
+xGMI is point-to-point (7 links per GPU): a ViT-B gradient set is 345 MB fp32; the default of one bucket per block
+(28 MB) keeps each ring step well above the latency floor while leaving 12 collectives in flight behind ~40 ms of
+backward compute; ``bucket_mb`` merges consecutive blocks into larger buckets (to be tuned against the measured RCCL bus
+bandwidth on an 8-GPU node: bench.py prints per-rank step times and the exposed all-reduce wait).
 """
 from typing import Iterable, List, Optional
 
@@ -25,11 +30,12 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, bucket_params: List[List[torch.nn.Parameter]], process_group=None):
-        """bucket_params[i] = parameters of bucket i, in the order buckets become ready; the last bucket is
-        the tail reduced by finish()."""
+    def __init__(self, bucket_params: List[List[torch.nn.Parameter]], process_group=None, blocks_per_bucket=None):
+        """bucket_params[i] = parameters of bucket i, in the order buckets become ready; the last bucket is the tail reduced
+        by finish().  blocks_per_bucket[i] (optional) = how many block_done calls complete bucket i (default 1)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.grad_scale = 1.0 / self.world
         self.buckets = []
         params = [p for b in bucket_params for p in b]
         if not params:
@@ -37,29 +43,50 @@ class GradReducer:
         dev, total = params[0].device, sum(p.numel() for p in params)
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         off = 0
-        for bp in bucket_params:
+        self._bucket_of = {}
+        for i, bp in enumerate(bucket_params):
             start = off
             for p in bp:
                 p.grad = self.flat[off:off + p.numel()].view_as(p)
+                self._bucket_of[id(p)] = i
                 off += p.numel()
             self.buckets.append((start, off))
-        self._index = {id(bp[0]): i for i, bp in enumerate(bucket_params) if bp}
+        self._need = list(blocks_per_bucket) if blocks_per_bucket else [1] * len(bucket_params)
+        self._have = [0] * len(bucket_params)
         self._handles = []
         self._launched = set()
 
     # -- called from inside backward ---------------------------------------------------------
-    def block_ready(self, layer: int, params: Iterable[torch.nn.Parameter], grads: List[Optional[torch.Tensor]]):
+    def grad_views(self, params: Iterable[torch.nn.Parameter]):
+        """The flat-buffer views of one block's parameters (what the backward kernels write into), or None when the
+        block is not bucketed (e.g. frozen)."""
         params = list(params)
-        i = self._index.get(id(params[0]))
-        if i is None:                      # not bucketed (e.g. frozen): let autograd handle it
+        if self._bucket_of.get(id(params[0])) is None:
+            return None
+        return [p.grad for p in params]
+
+    def block_done(self, params: Iterable[torch.nn.Parameter]):
+        """One block's gradients are in its views: count it, and launch the bucket's all-reduce when it is complete."""
+        i = self._bucket_of[id(next(iter(params)))]
+        self._have[i] += 1
+        if self._have[i] >= self._need[i]:
+            self._launch(i)
+
+    def block_ready(self, layer: int, params: Iterable[torch.nn.Parameter], grads: List[Optional[torch.Tensor]]):
+        """Hand-off of freshly computed gradient tensors (copied into the views); kept for callers that do not write in
+        place.  Returns what autograd should see (None: the gradients already sit in ``.grad``)."""
+        params = list(params)
+        views = self.grad_views(params)
+        if views is None:                  # not bucketed (e.g. frozen): let autograd handle it
             return grads
-        views, news = [], []
-        for p, g in zip(params, grads):
-            if g is not None:
-                views.append(p.grad)
-                news.append(g.view_as(p))
-        torch._foreach_add_(views, news)
-        self._launch(i)
+        dst, src = [], []
+        for v, g in zip(views, grads):
+            if g is not None and g.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(g.view_as(v))
+        if dst:
+            torch._foreach_copy_(dst, src)
+        self.block_done(params)
         return [None] * len(grads)
 
     def _launch(self, i):
@@ -69,37 +96,50 @@ class GradReducer:
         self._launched.add(i)
 
     # -- called after backward ---------------------------------------------------------------
-    def finish(self):
+    def finish(self, average=True):
+        """Reduce what is left, wait for everything.  average=True divides by the world size in place (stock optimizers);
+        average=False leaves SUMS and the caller passes ``grad_scale`` to FusedAdamW.step."""
         for i in range(len(self.buckets)):
             self._launch(i)
         for h in self._handles:
             h.wait()
         self._handles.clear()
         self._launched.clear()
-        if self.world > 1:
-            self.flat.mul_(1.0 / self.world)
+        self._have = [0] * len(self.buckets)
+        if average and self.world > 1:
+            self.flat.mul_(self.grad_scale)
 
     def zero_grad(self):
-        self.flat.zero_()
+        """Only the tail bucket accumulates (autograd adds into its views); the block buckets are overwritten."""
+        s, e = self.buckets[-1]
+        self.flat[s:e].zero_()
 
 
-def build_reducer(model, process_group=None) -> GradReducer:
-    """Buckets for a pix4point.Pix4Point: encoder blocks last-to-first, then every other parameter that can
-    receive a gradient.  Installs itself as the encoder's grad sink."""
+def build_reducer(model, process_group=None, bucket_mb=None) -> GradReducer:
+    """Buckets for a pix4point.Pix4Point: encoder blocks last-to-first (consecutive blocks merged until a bucket holds
+    at least ``bucket_mb`` MB; default: one block per bucket), then every other parameter that can receive a gradient.
+    Installs itself as the encoder's grad sink."""
     pv = model.model
     from .functional import block_params
     blocks = list(pv.vit_blocks)
-    buckets, seen = [], set()
+    buckets, counts, seen = [], [], set()
+    want = 0 if not bucket_mb else float(bucket_mb) * 1e6
     for blk in reversed(blocks):
         bp = [p for p in block_params(blk) if p.requires_grad]
         if bp and len(bp) == 12:
-            buckets.append(bp)
+            if buckets and counts[-1] and sum(p.numel() for p in buckets[-1]) * 4 < want:
+                buckets[-1] += bp
+                counts[-1] += 1
+            else:
+                buckets.append(bp)
+                counts.append(1)
             seen.update(id(p) for p in bp)
     unused = {id(p) for n, p in pv.vit.named_parameters()
               if n.startswith(('patch_embed.', 'head.')) or n == 'pos_embed'}
     tail = [p for p in model.parameters() if p.requires_grad and id(p) not in seen and id(p) not in unused]
     buckets.append(tail)
-    red = GradReducer(buckets, process_group)
+    counts.append(0)
+    red = GradReducer(buckets, process_group, blocks_per_bucket=counts)
     pv.grad_sink = red
     return red
 

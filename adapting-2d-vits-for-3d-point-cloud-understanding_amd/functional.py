@@ -343,6 +343,9 @@ class _EncoderFn(torch.autograd.Function):
             n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = bp[l * _BLOCK_PARAMS:(l + 1) * _BLOCK_PARAMS]
             xin, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, hpre, g = saved[l * 13:(l + 1) * 13]
             wg = need[8 + l * _BLOCK_PARAMS + 2]       # block weights trainable? (frozen ViT => False)
+            # data parallel: the weight-gradient GEMMs write straight into the reducer's flat buffer (ddp.GradReducer)
+            dst = sink.grad_views(bp[l * _BLOCK_PARAMS:(l + 1) * _BLOCK_PARAMS]) if (wg and sink is not None) else None
+            out_w = (lambda j: dst[j]) if dst is not None else (lambda j: None)
             # ---- mlp: x = x1 + fc2(gelu(fc1(ln2)))
             _, Wfc2T = _bf16_weights(fc2w, True)
             if wg and _FUSE_FC1_BIAS:        # fc1 bias gradient = column sums of dh, accumulated in the same epilogue
@@ -352,11 +355,11 @@ class _EncoderFn(torch.autograd.Function):
             _, Wfc1T = _bf16_weights(fc1w, True)
             dln2 = ops.gemm_tn(dh, Wfc1T, ops.EPI_BF16)
             if wg:
-                dfc2w, dfc2b = ops.gemm_wgrad(dxb, g), dx_colsum
+                dfc2w, dfc2b = ops.gemm_wgrad(dxb, g, out=out_w(10)), dx_colsum
                 if _FUSE_FC1_BIAS:
-                    dfc1w = ops.gemm_wgrad(dh, ln2)
+                    dfc1w = ops.gemm_wgrad(dh, ln2, out=out_w(8))
                 else:
-                    dfc1w, dfc1b = ops.gemm_wgrad(dh, ln2, want_bias=True)
+                    dfc1w, dfc1b = ops.gemm_wgrad(dh, ln2, out=out_w(8), want_bias=True)
             del dh
             _, dn2w, dn2b, dx_colsum = ops.layernorm_bwd(dln2, x1, mean2, rstd2, n2w.detach(), dx=dx, dx_bf16=dxb,
                                                          want_dxsum=True)
@@ -364,7 +367,7 @@ class _EncoderFn(torch.autograd.Function):
             _, WprojT = _bf16_weights(projw, True)
             datt = ops.gemm_tn(dxb, WprojT, ops.EPI_BF16)
             if wg:
-                dprojw, dprojb = ops.gemm_wgrad(dxb, att), dx_colsum
+                dprojw, dprojb = ops.gemm_wgrad(dxb, att, out=out_w(4)), dx_colsum
             fuse_qkvb = _FUSE_QKV_BIAS and T <= _FUSE_QKV_BIAS_MAXT
             if wg and fuse_qkvb:
                 dqkv, dqkvb = ops.attention_bwd(qkv, att, datt, lse, B, T, H, want_colsum=True)
@@ -374,9 +377,9 @@ class _EncoderFn(torch.autograd.Function):
             dln1 = ops.gemm_tn(dqkv, WqkvT, ops.EPI_BF16)
             if wg:
                 if fuse_qkvb:
-                    dqkvw = ops.gemm_wgrad(dqkv, ln1)
+                    dqkvw = ops.gemm_wgrad(dqkv, ln1, out=out_w(2))
                 else:
-                    dqkvw, dqkvb = ops.gemm_wgrad(dqkv, ln1, want_bias=True)
+                    dqkvw, dqkvb = ops.gemm_wgrad(dqkv, ln1, out=out_w(2), want_bias=True)
             del dqkv, datt
             _, dn1w, dn1b, dx_colsum = ops.layernorm_bwd(dln1, xin, mean1, rstd1, n1w.detach(), dx=dx, dx_bf16=dxb,
                                                          dacc=dpos, dacc_init=(l == L - 1), want_dxsum=True)

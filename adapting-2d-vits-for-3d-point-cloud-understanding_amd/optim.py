@@ -49,9 +49,11 @@ class FusedAdamW(torch.optim.Optimizer):
         return desc.to(dev, non_blocking=True), ch.to(dev, non_blocking=True), len(chunks)
 
     @torch.no_grad()
-    def step(self, closure=None, max_norm=None):
+    def step(self, closure=None, max_norm=None, grad_scale=1.0):
         """One AdamW update.  With ``max_norm`` the gradients are first scaled by min(1, max_norm / (||g||_2 + 1e-6)) over
-        ALL parameters of this optimizer (clip_grad_norm_ semantics); returns the total norm (0-dim device tensor)."""
+        ALL parameters of this optimizer (clip_grad_norm_ semantics); returns the total norm (0-dim device tensor).
+        ``grad_scale`` multiplies every gradient first (data parallel: the all-reduce leaves SUMS in ``.grad`` and 1/world
+        travels here, folded into the one factor the update kernel applies: no pass over the gradient buffer)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -89,7 +91,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if ident != self._key:
             self._tables = {}
             for key, es in by_hyper.items():
-                self._tables[key[:3]] = self._build_tables(es, dev)
+                self._tables[key[:3] + (len(es), id(es[0][0]))] = self._build_tables(es, dev)
             allt = self._build_tables(entries, dev)
             self._tables['all'] = allt + (torch.empty(allt[2], dtype=torch.float32, device=dev),
                                           torch.empty(2, dtype=torch.float32, device=dev))
@@ -97,13 +99,16 @@ class FusedAdamW(torch.optim.Optimizer):
         stream = L.ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         coef = None
         total_norm = None
-        if max_norm is not None:
+        if max_norm is not None or grad_scale != 1.0:
             desc, ch, n, partial, out = self._tables['all']
             L.call('p4p_grad_sumsq', L.ptr(desc), L.ptr(ch), n, L.ptr(partial), stream)
-            L.call('p4p_clip_coef', L.ptr(partial), n, float(max_norm), L.ptr(out), stream)
+            L.call('p4p_clip_coef', L.ptr(partial), n, float(max_norm) if max_norm is not None else float('inf'),
+                   float(grad_scale), L.ptr(out), stream)
             coef, total_norm = out, out[1]
-        for (beta1, beta2, eps, step), _ in by_hyper.items():
-            desc, ch, n = self._tables[(beta1, beta2, eps)][:3]
+        for (beta1, beta2, eps, step), es in by_hyper.items():
+            # one table per (betas, eps, STEP COUNT) subset: parameters that share the hyper-parameters but not the step
+            # count (first gradient later, added group, mixed loaded state) get their own bias corrections
+            desc, ch, n = self._tables[(beta1, beta2, eps, len(es), id(es[0][0]))][:3]
             L.call('p4p_adamw_step', L.ptr(desc), L.ptr(ch), n, L.ptr(coef), float(beta1), float(beta2), float(eps),
                    float(1.0 - beta1 ** step), float(1.0 - beta2 ** step), stream)
         # the update kernel wrote the parameters through raw pointers: tell torch (autograd's in-place checks, and the

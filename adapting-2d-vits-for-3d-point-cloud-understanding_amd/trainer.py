@@ -73,7 +73,8 @@ class Pix4PointTrainer:
                                frozen=c['frozen'])
         self.model.to(self.device)
         broadcast_parameters(self.model)
-        self.reducer = build_reducer(self.model) if self.distributed else None
+        self.reducer = (build_reducer(self.model, bucket_mb=self.train_config.get('ddp_bucket_mb'))
+                        if self.distributed else None)      # 'ddp_bucket_mb': additive key (the reference has no DDP)
         if self.rank == 0:
             self.model.print_trainable_params()
 
@@ -154,10 +155,13 @@ class Pix4PointTrainer:
         logits = self.model(points, start_idx)
         loss = self.criterion(logits, labels)
         loss.backward()
+        fused = isinstance(self.optimizer, FusedAdamW)
+        scale = 1.0
         if self.reducer is not None:
-            self.reducer.finish()
-        if isinstance(self.optimizer, FusedAdamW):
-            self.optimizer.step(max_norm=self.train_config['grad_norm_clip'])
+            self.reducer.finish(average=not fused)        # fused: .grad holds SUMS, 1/world rides in the clip coefficient
+            scale = self.reducer.grad_scale if fused else 1.0
+        if fused:
+            self.optimizer.step(max_norm=self.train_config['grad_norm_clip'], grad_scale=scale)
         else:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.train_config['grad_norm_clip'], foreach=True)
             self.optimizer.step()

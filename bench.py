@@ -89,7 +89,7 @@ class Stepper:
                                            pretrained=False, k_neighbors=16).to(device)
         self.model.train()
         broadcast_parameters(self.model)
-        self.reducer = build_reducer(self.model) if distributed else None
+        self.reducer = build_reducer(self.model, bucket_mb=args.bucket_mb) if distributed else None
         from p4p_amd.optim import FusedAdamW
         if os.environ.get('P4P_TORCH_OPTIM'):         # A/B: stock torch clip + fused AdamW
             self.opt = torch.optim.AdamW(self.model.get_param_groups(), lr=5e-4, weight_decay=5e-2, fused=True)
@@ -107,12 +107,14 @@ class Stepper:
             self.opt.zero_grad(set_to_none=True)
         loss = self.crit(self.model(pts, start), labels)
         loss.backward()
+        scale = 1.0
         if self.reducer is not None:
-            self.reducer.finish()
+            self.reducer.finish(average=not self.fused_opt)     # fused: sums stay, 1/world rides in the clip coefficient
+            scale = self.reducer.grad_scale if self.fused_opt else 1.0
         if not optim:
             return loss
         if self.fused_opt:
-            self.opt.step(max_norm=10)               # clip_grad_norm_ + AdamW in three launches (p4p_amd.optim)
+            self.opt.step(max_norm=10, grad_scale=scale)        # clip_grad_norm_ + AdamW in three launches (p4p_amd.optim)
         else:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=10, foreach=True)
             self.opt.step()
@@ -147,9 +149,9 @@ class ApfStepper:
         loss = self.crit(self.model(pts, start), labels)
         loss.backward()
         if self.reducer is not None:
-            self.reducer.finish()
+            self.reducer.finish(average=False)
         if optim:
-            self.opt.step()
+            self.opt.step(grad_scale=self.reducer.grad_scale if self.reducer is not None else 1.0)
         return loss
 
 
@@ -377,10 +379,14 @@ def allreduce_exposed_ms(stepper, batch, steps=3):
         loss.backward()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        stepper.reducer.finish()
+        stepper.reducer.finish(average=False)
         torch.cuda.synchronize()
         tot += time.perf_counter() - t0
-        stepper.opt.step(max_norm=10) if getattr(stepper, 'fused_opt', False) else stepper.opt.step()
+        if getattr(stepper, 'fused_opt', True):
+            stepper.opt.step(max_norm=10 if hasattr(stepper, 'fused_opt') else None, grad_scale=stepper.reducer.grad_scale)
+        else:
+            stepper.reducer.flat.mul_(stepper.reducer.grad_scale)
+            stepper.opt.step()
     return tot / steps * 1e3
 
 
@@ -398,6 +404,8 @@ def main():
     ap.add_argument('--classes', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--bucket-mb', type=float, default=None,
+                    help='gradient all-reduce bucket size (default: one bucket per transformer block, 28 MB for ViT-B)')
     ap.add_argument('--no-north-star', action='store_true',
                     help='skip the extra N=2048, B=256 measurement (the point north_star states its targets at)')
     args = ap.parse_args()

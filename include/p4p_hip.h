@@ -188,8 +188,10 @@ int p4p_pos_mlp0_bwd(const float* x, const float* W, const float* b, const float
 int p4p_opt_chunk_elems(void);
 /* partial[c] = sum of squares of gradient chunk c */
 int p4p_grad_sumsq(const void* tensors, const void* chunks, int nchunks, float* partial, void* stream);
-/* coef_and_norm[0] = min(1, max_norm / (norm + 1e-6)), [1] = norm = sqrt(sum partial)  (torch.nn.utils.clip_grad_norm_) */
-int p4p_clip_coef(const float* partial, int nchunks, float max_norm, float* coef_and_norm, void* stream);
+/* norm = grad_scale * sqrt(sum partial); coef_and_norm[0] = grad_scale * min(1, max_norm / (norm + 1e-6)), [1] = norm
+   (torch.nn.utils.clip_grad_norm_ on gradients scaled by grad_scale: the data-parallel 1/world folded into the factor the
+   update kernel applies anyway; max_norm = +inf disables the clip; a NaN norm gives a NaN factor, as torch's clamp does) */
+int p4p_clip_coef(const float* partial, int nchunks, float max_norm, float grad_scale, float* coef_and_norm, void* stream);
 /* torch.optim.AdamW update (amsgrad=False) with g scaled by *coef (NULL = 1); bc1 = 1 - beta1^t, bc2 = 1 - beta2^t */
 int p4p_adamw_step(const void* tensors, const void* chunks, int nchunks, const float* coef, float beta1, float beta2,
                    float eps, float bc1, float bc2, void* stream);

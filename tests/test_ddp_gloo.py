@@ -63,6 +63,24 @@ def _worker(rank, world, port, out):
                 assert torch.allclose(p.grad, want, rtol=1e-6, atol=1e-7)
                 assert p.grad.data_ptr() >= red.flat.data_ptr()          # still a view of the flat buffer
             assert all(p.grad is None for p in unused.parameters())
+        # merged buckets (two blocks per all-reduce) and the sums + grad_scale hand-off the fused optimizer uses
+        red2 = GradReducer([list(blocks[2].parameters()) + list(blocks[1].parameters()), list(blocks[0].parameters()),
+                            list(tail.parameters())], blocks_per_bucket=[2, 1, 0])
+        assert red2.grad_scale == 1.0 / world
+        red2.zero_grad()
+        g = torch.Generator().manual_seed(7 + rank)
+        local = [torch.randn(p.shape, generator=g) for b in blocks for p in b.parameters()]
+        for l in reversed(range(3)):
+            views = red2.grad_views(list(blocks[l].parameters()))
+            views[0].copy_(local[2 * l])                              # a kernel writing straight into the view
+            ret = red2.block_ready(l, list(blocks[l].parameters()), [views[0], local[2 * l + 1]])
+            assert ret == [None, None]
+            assert len(red2._handles) == (0 if l == 2 else 1 if l == 1 else 2)      # bucket 0 waits for its second block
+        red2.finish(average=False)
+        for p, gl in zip([p for b in blocks for p in b.parameters()], local):
+            both = [torch.zeros_like(gl) for _ in range(world)]
+            dist.all_gather(both, gl)
+            assert torch.allclose(p.grad, sum(both), rtol=1e-6, atol=1e-7)         # SUMS: 1/world travels as grad_scale
         out.put((rank, 'ok'))
     except Exception as e:                            # pragma: no cover
         out.put((rank, repr(e)))

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, bucket_mb=None):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -50,9 +50,12 @@ def _worker(rank, world, port, q):
         for b, v in zip(model.buffers(), bufs):
             b.copy_(v)
 
-        red = build_reducer(model)
+        red = build_reducer(model, bucket_mb=bucket_mb)
+        assert len(red.buckets) == (2 if bucket_mb else 3)      # 2 blocks (+ tail); merged into one bucket when asked
         opt = torch.optim.AdamW(model.get_param_groups(), lr=1e-3, weight_decay=5e-2, fused=True)
         red.zero_grad()
+        red.flat.fill_(float('nan'))                            # the block buckets are OVERWRITTEN by the backward kernels ...
+        red.zero_grad()                                         # ... only the tail bucket accumulates and is zeroed
         torch.nn.functional.cross_entropy(model(pts, start), labels).backward()
         red.finish()
         worst = 0.0
@@ -66,8 +69,18 @@ def _worker(rank, world, port, q):
             err = float((p.grad - want).abs().max()) / max(float(want.abs().max()), 1e-6)
             worst = max(worst, err)
         assert worst < 1e-5, worst                          # same kernels, same inputs: only summation order differs
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0, foreach=True)
+        # the fused tail on SUMS with 1/world folded into the clip coefficient == stock clip + AdamW on the averages
+        from p4p_amd.optim import FusedAdamW
+        import copy
+        twin = copy.deepcopy(model)
+        for (n, p), (_, t) in zip(model.named_parameters(), twin.named_parameters()):
+            t.grad = None if p.grad is None else (p.grad * world).clone()       # what finish(average=False) leaves
+        fopt = FusedAdamW(twin.get_param_groups(), lr=1e-3, weight_decay=5e-2)
+        fopt.step(max_norm=0.05, grad_scale=red.grad_scale)                     # a clip that really bites
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.05, foreach=True)
         opt.step()
+        for (n, p), (_, t) in zip(model.named_parameters(), twin.named_parameters()):
+            assert torch.allclose(p, t, rtol=1e-5, atol=1e-7), n
         for n, p in model.named_parameters():
             g = [torch.zeros_like(p.data) for _ in range(world)]
             dist.all_gather(g, p.data)
@@ -81,11 +94,12 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_step_on_one_gpu():
+@pytest.mark.parametrize('bucket_mb', [None, 100.0])
+def test_two_rank_data_parallel_step_on_one_gpu(bucket_mb):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, bucket_mb)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
@@ -114,3 +128,4 @@ def test_bench_two_rank_control_flow_on_one_gpu(tmp_path):
         d = json.loads(lines[0])
         assert d['n_gpus'] == 2 and d['steps'] == 2 and d['config']['global_batch'] == 32 and d['config']['parallelism'] == 'dp2'
         assert d['value'] > 0 and 'roofline' in d and d['roofline']['achieved'] > 0
+        assert len(d['per_rank_ms_per_step']) == 2 and d['allreduce_exposed_ms'] >= 0 and d['fwd_bwd_only']['value'] > 0

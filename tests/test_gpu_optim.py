@@ -92,3 +92,54 @@ def test_step_invalidates_the_bf16_operand_caches():
     assert w._version > v0
     wb1, _ = _bf16_weights(w, False)
     assert wb1 is not wb0 and torch.equal(wb1, w.detach().bfloat16()) and not torch.equal(wb1, wb0)
+
+
+def test_parameters_with_different_step_counts_get_their_own_bias_correction():
+    """parameters that share betas / eps but not the step count (here: two of them receive their first gradient
+    at step 3) must each be updated exactly once per step with THEIR bias correction, as torch.optim.AdamW does."""
+    from p4p_amd.optim import FusedAdamW
+    ours, ref = _params(3, DEV), _params(3, 'cpu')
+    opt = FusedAdamW([{'params': ours}], lr=1e-3, weight_decay=5e-2)
+    tor = torch.optim.AdamW([{'params': ref}], lr=1e-3, weight_decay=5e-2)
+    late = {1, 5}
+    for it in range(5):
+        gs = _grads(ref, 300 + it, 1.0)
+        for j, (p, q, g) in enumerate(zip(ours, ref, gs)):
+            if j in late and it < 2:
+                p.grad = q.grad = None
+            else:
+                p.grad, q.grad = g.to(DEV), g.clone()
+        want_norm = torch.nn.utils.clip_grad_norm_([q for q in ref if q.grad is not None], 5.0)
+        tor.step()
+        got_norm = opt.step(max_norm=5.0)
+        torch.testing.assert_close(got_norm.cpu(), want_norm, rtol=1e-5, atol=1e-7)
+        for p, q in zip(ours, ref):
+            torch.testing.assert_close(p.detach().cpu(), q.detach(), rtol=2e-6, atol=2e-7)
+    assert float(opt.state[ours[1]]['step']) == 3 and float(opt.state[ours[0]]['step']) == 5
+
+
+def test_grad_scale_is_the_data_parallel_mean_and_nan_norms_propagate():
+    """grad_scale (1/world of the gradient all-reduce) folded into the clip coefficient == scaling the gradients first; a NaN
+    gradient norm poisons the update as torch.nn.utils.clip_grad_norm_ does (its clamp keeps NaN), it is not clipped away."""
+    from p4p_amd.optim import FusedAdamW
+    for max_norm in (None, 0.5):
+        ours, ref = _params(4, DEV), _params(4, 'cpu')
+        opt = FusedAdamW([{'params': ours}], lr=1e-3, weight_decay=5e-2)
+        tor = torch.optim.AdamW([{'params': ref}], lr=1e-3, weight_decay=5e-2)
+        for it in range(3):
+            gs = _grads(ref, 400 + it, 1.0)
+            for p, q, g in zip(ours, ref, gs):
+                p.grad, q.grad = (g * 8).to(DEV), g.clone()                    # a sum over 8 ranks vs its mean
+            if max_norm is not None:
+                torch.nn.utils.clip_grad_norm_(ref, max_norm)
+            tor.step()
+            opt.step(max_norm=max_norm, grad_scale=1.0 / 8)
+            for p, q in zip(ours, ref):
+                torch.testing.assert_close(p.detach().cpu(), q.detach(), rtol=2e-6, atol=2e-7)
+    ours = _params(5, DEV)
+    opt = FusedAdamW([{'params': ours}], lr=1e-3)
+    for p in ours:
+        p.grad = torch.ones_like(p)
+    ours[2].grad[0] = float('nan')
+    norm = opt.step(max_norm=1.0)
+    assert bool(torch.isnan(norm)) and all(bool(torch.isnan(p).any()) for p in ours)
