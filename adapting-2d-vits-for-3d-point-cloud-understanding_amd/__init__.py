@@ -11,3 +11,4 @@ from .pix4point import (ClsHead, P3Embed, Pix4Point, PointViT, farthest_point_sa
 from .apf import AdaptPointFormer  # noqa: F401
 from .apf_trainer import APFTrainer  # noqa: F401
 from .scanobjectnn import ScanObjectNN  # noqa: F401
+from .functional import invalidate_operand_caches  # noqa: F401

@@ -1070,6 +1070,11 @@ __global__ __launch_bounds__(RES_DKDV_NW * 64, 2) void attn_bwd_dkdv_res_kernel(
 
 #include "attention_lone.h"
 
+// experiment switch for tools/attn_ab.py (in-process A/B, default 0 = automatic): bit 0 = no resident forward / dQ,
+// bit 1 = no resident dK/dV, bit 2 = no two-pass (64 n + 1) forward.  Nothing in the product path sets it.
+static int g_attn_variant = 0;
+extern "C" int p4p_set_attention_variant(int v) { int o = g_attn_variant; g_attn_variant = v; return o; }
+
 static int check_attn(const char* fn, int B, int T, int H, int D) {
     P4P_CHECK(B >= 1 && T >= 1 && H >= 1, "%s: bad sizes B=%d T=%d H=%d", fn, B, T, H);
     P4P_CHECK(D == H * HD, "%s: only head_dim 64 is built (D=%d, H=%d)", fn, D, H);
@@ -1084,8 +1089,7 @@ extern "C" int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B,
     AttnParams p = {};
     p.qkv = (const __bf16*)qkv; p.out = (__bf16*)out; p.lse2 = lse2; p.B = B; p.T = T; p.H = H; p.D = D; p.scale = scale;
     const bool prof = p4p_prof_begin(3, 4.0 * B * H * (double)T * T * HD, (hipStream_t)stream);      // bench.py: attention forward
-    static const bool no_res = getenv("P4P_ATTN_NO_RES") != nullptr;          // A/B switch (tools/ab_bench.sh)
-    static const bool no_lone = getenv("P4P_ATTN_NO_LONE") != nullptr;        // A/B switch
+    const bool no_res = g_attn_variant & 1, no_lone = g_attn_variant & 4;
     if (T % 64 == 1 && T >= 65 && T <= 257 && !no_lone) {                    // 64 n + 1 rows: attention_lone.h
         const dim3 grid(B * H), block(LONE_NW * 64);
         switch ((T - 1) / 64) {
@@ -1098,8 +1102,7 @@ extern "C" int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B,
         hipLaunchKernelGGL(attn_fwd_res_kernel, dim3(B * H), dim3(RES_NW * 64), 0, (hipStream_t)stream, p);
     else {
         // measured at B=256, H=12 (tools/attn_ab.py): T=513: 542 / 499 / 533 us for 1 / 2 / 4 tiles per wave; T=2049: 5398 / 4643 / 4501
-        static const int env_qt = getenv("P4P_ATTN_FWD_QT") ? atoi(getenv("P4P_ATTN_FWD_QT")) : 0;   // A/B switch
-        const int qt = env_qt ? env_qt : (T >= 1024 ? 4 : 2);
+        const int qt = T >= 1024 ? 4 : 2;
         if (qt == 2 && T > 128)
             hipLaunchKernelGGL(attn_fwd_q_kernel<2>, dim3((unsigned)(ceil_div((long long)B * H, 8) * 8 * ceil_div(T, 128))),
                                dim3(ATT_THREADS), 0, (hipStream_t)stream, p);
@@ -1116,12 +1119,10 @@ extern "C" int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B,
 
 // dqkv receives dq | dk | dv in the layout of qkv.  delta is [B,H,T] workspace.
 static bool attn_resident(int T) {
-    static const bool no_res = getenv("P4P_ATTN_NO_RES") != nullptr;          // A/B switch (tools/ab_bench.sh)
-    return T <= RES_ROWS - 31 && T >= 64 && !no_res;
+    return T <= RES_ROWS - 31 && T >= 64 && !(g_attn_variant & 1);
 }
 static bool attn_resident_dkdv(int T) {
-    static const bool on = getenv("P4P_ATTN_NO_RES_DKDV") == nullptr;          // A/B switch; 4 waves x 220 VGPRs: -0.4 ms/step
-    return on && attn_resident(T);
+    return !(g_attn_variant & 2) && attn_resident(T);       // 4 waves x 220 VGPRs: -0.4 ms/step
 }
 // the partial-row layouts of the streaming and the resident kernels differ: dq and dk/dv take the same path when sums are asked for
 extern "C" int p4p_attention_colsum_rows(int B, int T) { return attn_resident_dkdv(T) ? B * RES_COLSUM_ROWS : B * ceil_div(T, 64) * 4; }
@@ -1142,8 +1143,7 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
     } prof_scope(10.0 * B * H * (double)T * T * HD, st);
     const bool res_dkdv = attn_resident_dkdv(T);
     const bool res = attn_resident(T) && (res_dkdv || !colsum_partial);
-    static const int env_dq_qt = getenv("P4P_ATTN_DQ_QT") ? atoi(getenv("P4P_ATTN_DQ_QT")) : 0;       // A/B switch (tools/attn_ab.py)
-    const bool dq_q = !res && (env_dq_qt ? env_dq_qt : 2) == 2 && T > 128;
+    const bool dq_q = !res && T > 128;                   // two query tiles per wave
     if (!res && !dq_q) {                                 // the resident and the two-tile dQ kernels compute delta themselves
         hipLaunchKernelGGL(attn_delta_kernel, dim3(ceil_div((long long)B * T, 4)), dim3(256), 0, st, (const __bf16*)o,
                            (const __bf16*)dout, delta, B, T, H, D);

@@ -62,6 +62,46 @@ __global__ __launch_bounds__(256) void cast_transpose4_kernel(const float* __res
     }
 }
 
+// Many weights in ONE launch (the per-step refresh of the encoder's 4 L operand pairs: 48 launches of ~7 us -> 1).  Every
+// tensor obeys the cast_transpose4 conditions (multiples of 4, aligned); block -> (tensor, 64 x 64 tile) through the prefix
+// of tile counts.
+struct P4PCastDesc { const float* src; __bf16* dst; __bf16* dstT; long long ld; int R, C; int tile0, tiles_c; };
+__global__ __launch_bounds__(256) void cast_transpose4_multi_kernel(const P4PCastDesc* __restrict__ descs, int n) {
+    __shared__ float tile[64][65];
+    int lo = 0, hi = n - 1;                                  // last tensor whose first tile is <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const P4PCastDesc d = descs[lo];
+    const int tl = blockIdx.x - d.tile0;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int r0 = (tl / d.tiles_c) * 64, c0 = (tl % d.tiles_c) * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + ty + j * 16, c = c0 + tx * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < d.R && c < d.C) v = *reinterpret_cast<const f32x4*>(d.src + (size_t)r * d.ld + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tile[ty + j * 16][tx * 4 + i] = v[i];
+        if (d.dst && r < d.R && c < d.C) {
+            const bf16x4 w = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            *reinterpret_cast<bf16x4*>(d.dst + (size_t)r * d.C + c) = w;
+        }
+    }
+    if (!d.dstT) return;                                     // block-uniform
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + ty + j * 16, r = r0 + tx * 4;
+        if (r < d.R && c < d.C) {
+            const bf16x4 w = {f2bf(tile[tx * 4][ty + j * 16]), f2bf(tile[tx * 4 + 1][ty + j * 16]),
+                              f2bf(tile[tx * 4 + 2][ty + j * 16]), f2bf(tile[tx * 4 + 3][ty + j * 16])};
+            *reinterpret_cast<bf16x4*>(d.dstT + (size_t)c * d.R + r) = w;
+        }
+    }
+}
+
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long long n) {
     long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (e + 3 < n) {
@@ -202,6 +242,18 @@ extern "C" int p4p_cast_transpose_f32_bf16(const float* src, long long ld_src, v
     else
         hipLaunchKernelGGL(cast_transpose_kernel, dim3(ceil_div(C, 32), ceil_div(R, 32)), dim3(256), 0,
                            (hipStream_t)stream, src, ld_src, (__bf16*)dst, (__bf16*)dstT, R, C);
+    P4P_LAUNCH_CHECK();
+    return 0;
+}
+
+// descs: DEVICE array of n records {const float* src; bf16* dst; bf16* dstT; long long ld; int R, C; int tile0, tiles_c}
+// (48 bytes each; tile0 = number of 64 x 64 tiles of the records before it, tiles_c = ceil(C / 64)); total_tiles = grid size.
+// Every record must satisfy R, C, ld % 4 == 0, src 16-byte and dst / dstT 8-byte aligned (the caller checks: the table is
+// device memory).
+extern "C" int p4p_cast_transpose_multi(const void* descs, int n, int total_tiles, void* stream) {
+    P4P_CHECK(descs && n >= 1 && total_tiles >= 1, "p4p_cast_transpose_multi: bad arguments");
+    hipLaunchKernelGGL(cast_transpose4_multi_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream,
+                       (const P4PCastDesc*)descs, n);
     P4P_LAUNCH_CHECK();
     return 0;
 }

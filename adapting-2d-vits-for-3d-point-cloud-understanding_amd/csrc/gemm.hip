@@ -131,7 +131,7 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
             const int tiles_n = ceil_div(p.N, bn), tiles_m = ceil_div(p.M, 256);       // the last panel may be ragged: it is peeled first
             const long long total = (long long)tiles_m * tiles_n;
             const long long rounds = total / slots, rem = total % slots;
-            static const int peel_max_rounds = getenv("P4P_PEEL_MAX_ROUNDS") ? atoi(getenv("P4P_PEEL_MAX_ROUNDS")) : 12;   // narrow N (<= 4 tiles per panel): measured at N=2048 (6 rounds + 3 tiles)
+            const int peel_max_rounds = 12;     // narrow N (<= 4 tiles per panel): measured at N=2048 (6 rounds + 3 tiles)
             if (rounds >= 1 && rounds <= (tiles_n <= 4 ? peel_max_rounds : 4) && rem > 0 && rem * 8 <= slots && rem % tiles_n == 0 && rem / tiles_n < tiles_m) {
                 GemmParams a = p, b = p;
                 a.M = (tiles_m - (int)(rem / tiles_n)) * 256;           // whole panels for the big-tile launch
@@ -151,8 +151,7 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
                 if (!rc) {
                     int splits = 1;
                     if constexpr (EPI == EPI_BF16 || EPI == EPI_F32_RESID) {
-                        static const bool no_splitk = getenv("P4P_NO_SPLITK") != nullptr;    // A/B switch for tools/ab_bench.sh
-                        if (p.K >= 1536 && p.N % 4 == 0 && !no_splitk) {    // long K: slices of 768 (or 512) columns
+                        if (p.K >= 1536 && p.N % 4 == 0) {    // long K: slices of 768 (or 512) columns
                             splits = p.K % 768 == 0 ? p.K / 768 : (p.K % 512 == 0 ? p.K / 512 : 1);
                             if (splits > 8) splits = 1;
                         }

@@ -7,8 +7,6 @@
 Forward and backward both run hand-written kernels; torch is only the allocator, the stream and
 the autograd graph.  Saved activations are bf16 except the fp32 residual stream.
 """
-import os
-
 import torch
 
 from . import ops
@@ -33,6 +31,73 @@ def _bf16_weights(w, want_t, col0=0, cols=None):
     wb, wt = ops.cast_weight(w.detach(), True, want_t, cols=cols, col0=col0)
     cache[(col0, cols)] = (w._version, wb, wt, w.data_ptr())
     return wb, wt
+
+
+_multi_tables = {}        # tuple of pointers -> (device descriptor table, tiles)
+
+
+def refresh_weight_operands(weights, want_t):
+    """Re-make the bf16 operand copies (W and, if want_t, W^T) of every STALE weight in ``weights`` (2-D fp32 parameters, whole
+    matrices) in ONE launch, in place in their existing buffers; afterwards _bf16_weights() hits the cache for all of them.
+    After an optimizer step that is every weight of the encoder: one launch instead of one per weight."""
+    stale = []
+    for w in weights:
+        cache = getattr(w, '_p4p_bf16', None)
+        ent = cache.get((0, None)) if cache else None
+        if (ent is not None and ent[0] == w._version and ent[3] == w.data_ptr() and (ent[2] is not None or not want_t)):
+            continue
+        R, C = w.shape[0], w[0].numel()
+        if w.dim() != 2 or R % 4 or C % 4 or w.data_ptr() % 16 or not w.is_contiguous():
+            continue                                   # left to the per-tensor path of _bf16_weights
+        stale.append((w, ent))
+    if len(stale) < 2:
+        return 0
+    recs = []
+    for w, ent in stale:
+        R, C = w.shape
+        wb = ent[1] if ent is not None else torch.empty(R, C, dtype=torch.bfloat16, device=w.device)
+        wt = ent[2] if (ent is not None and ent[2] is not None) else (
+            torch.empty(C, R, dtype=torch.bfloat16, device=w.device) if want_t else None)
+        recs.append((w, wb, wt))
+    key = tuple((w.data_ptr(), wb.data_ptr(), 0 if wt is None else wt.data_ptr()) for w, wb, wt in recs)
+    tab = _multi_tables.get(key)
+    if tab is None:
+        import struct
+        raw, tile0 = bytearray(), 0
+        for w, wb, wt in recs:
+            R, C = w.shape
+            tc = (C + 63) // 64
+            raw += struct.pack('<QQQqiiii', w.data_ptr(), wb.data_ptr(), 0 if wt is None else wt.data_ptr(), C, R, C, tile0, tc)
+            tile0 += tc * ((R + 63) // 64)
+        host = torch.frombuffer(raw, dtype=torch.uint8).clone().pin_memory()
+        if len(_multi_tables) > 16:
+            _multi_tables.clear()
+        tab = (host.to(recs[0][0].device, non_blocking=True), tile0, host)        # host kept alive with its copy
+        _multi_tables[key] = tab
+    ops.cast_weights_multi(tab[0], len(recs), tab[1])
+    for w, wb, wt in recs:
+        cache = getattr(w, '_p4p_bf16', None)
+        if cache is None:
+            cache = {}
+            w._p4p_bf16 = cache
+        cache[(0, None)] = (w._version, wb, wt, w.data_ptr())
+    return len(recs)
+
+
+def invalidate_operand_caches(module):
+    """Drop the cached bf16 operand copies of every parameter of ``module`` (they are re-made at the next forward).
+
+    The caches are keyed on the parameter's version counter and data pointer, which every in-place torch op and this
+    package's own raw-pointer writers (FusedAdamW.step, ddp.broadcast_parameters) advance.  A write that bypasses the
+    counter -- ``p.data.copy_(...)``, a third-party kernel, EMA / SWA code that goes through ``.data`` -- leaves STALE
+    weights in forward and backward without an error; call this after such a write (load_checkpoint does)."""
+    n = 0
+    for p in module.parameters():
+        for attr in ('_p4p_bf16', '_p4p_scaled', '_p4p_up'):
+            if hasattr(p, attr):
+                delattr(p, attr)
+                n += 1
+    return n
 
 
 # ================================================================================================
@@ -257,14 +322,11 @@ def token_stream(x, weight, bias, cls_vec):
 # ViT encoder: L blocks + final norm
 # ================================================================================================
 _BLOCK_PARAMS = 12     # n1w n1b qkvw qkvb projw projb n2w n2b fc1w fc1b fc2w fc2b
-# bias gradients of qkv / fc1 from inside the kernels that produce dqkv / dh (A/B switches for tools/, default on)
-_FUSE_QKV_BIAS = os.environ.get('P4P_FUSE_QKV_BIAS', '1') != '0'   # -0.75 ms/step with the resident attention kernels (T <= 257)
-# above this T the column sums of dqkv take a separate pass.  A/B in one call: T=513 (N=2048, B=256) 114.6 -> 113.35 ms fused;
-# T=2049 (ViT-L, B=16) 119.65 vs 119.57: no difference, left on the separate pass
-_FUSE_QKV_BIAS_MAXT = int(os.environ.get('P4P_FUSE_QKV_BIAS_MAXT', '1024'))
-_FUSE_FC1_BIAS = os.environ.get('P4P_FUSE_FC1_BIAS', '1') != '0'
-# blk(x + pos) (src/models/pix4point.py:255): the fc2 epilogue of block l adds pos for block l+1 (A/B switch)
-_POS_IN_FC2 = os.environ.get('P4P_POS_IN_FC2', '1') != '0'
+# Settled by in-step A/B measurements, fixed here rather than switchable:
+# * the bias gradients of qkv / fc1 come out of the kernels that produce dqkv / dh (no separate column-sum pass); for the
+#   qkv bias only up to T = 1024 (T = 513: 114.6 -> 113.35 ms per step fused; T = 2049: no difference, separate pass kept);
+# * blk(x + pos) (src/models/pix4point.py:255): the fc2 epilogue of block l adds pos for block l + 1.
+_FUSE_QKV_BIAS_MAXT = 1024
 
 
 def block_params(blk):
@@ -287,7 +349,7 @@ class _EncoderFn(torch.autograd.Function):
         saved = []
         for l in range(L):
             n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = bp[l * _BLOCK_PARAMS:(l + 1) * _BLOCK_PARAMS]
-            if l == 0 or not _POS_IN_FC2:
+            if l == 0:
                 ln1, xin, mean1, rstd1 = ops.layernorm_fwd(x, n1w.detach(), n1b.detach(), eps, pos=pos2, want_sum=True,
                                                            want_stats=train)
             else:       # x already is x_l + pos: the fc2 epilogue of the block below added it (one stream in, no sum written)
@@ -306,12 +368,12 @@ class _EncoderFn(torch.autograd.Function):
                 g, hpre = ops.gemm_tn(ln2, Wfc1, ops.EPI_BF16_GELU, bias=fc1b.detach()), None
             Wfc2, _ = _bf16_weights(fc2w, train)
             x = ops.gemm_tn(g, Wfc2, ops.EPI_F32_RESID, bias=fc2b.detach(), resid=x1,
-                            resid2=pos2 if (_POS_IN_FC2 and l + 1 < L) else None)
+                            resid2=pos2 if l + 1 < L else None)
             if train:
                 saved += [xin, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, hpre, g]
             if _CAPTURE is not None:
                 _CAPTURE.setdefault('blocks', []).append(dict(xin=xin, ln1=ln1, qkv=qkv, att=att, x1=x1, ln2=ln2, g=g, xout=x,
-                                                              pos_added=bool(_POS_IN_FC2 and l + 1 < L)))
+                                                              pos_added=l + 1 < L))
         y, _, meanN, rstdN = ops.layernorm_fwd(x, norm_w.detach(), norm_b.detach(), eps, out_f32=True, want_stats=train)
         if _CAPTURE is not None:
             _CAPTURE['encoder_out'] = y
@@ -348,7 +410,7 @@ class _EncoderFn(torch.autograd.Function):
             out_w = (lambda j: dst[j]) if dst is not None else (lambda j: None)
             # ---- mlp: x = x1 + fc2(gelu(fc1(ln2)))
             _, Wfc2T = _bf16_weights(fc2w, True)
-            if wg and _FUSE_FC1_BIAS:        # fc1 bias gradient = column sums of dh, accumulated in the same epilogue
+            if wg:                           # fc1 bias gradient = column sums of dh, accumulated in the same epilogue
                 dh, dfc1b = ops.gemm_tn(dxb, Wfc2T, ops.EPI_BF16_DGELU, pre=hpre, want_colsum=True)
             else:
                 dh = ops.gemm_tn(dxb, Wfc2T, ops.EPI_BF16_DGELU, pre=hpre)
@@ -356,10 +418,7 @@ class _EncoderFn(torch.autograd.Function):
             dln2 = ops.gemm_tn(dh, Wfc1T, ops.EPI_BF16)
             if wg:
                 dfc2w, dfc2b = ops.gemm_wgrad(dxb, g, out=out_w(10)), dx_colsum
-                if _FUSE_FC1_BIAS:
-                    dfc1w = ops.gemm_wgrad(dh, ln2, out=out_w(8))
-                else:
-                    dfc1w, dfc1b = ops.gemm_wgrad(dh, ln2, out=out_w(8), want_bias=True)
+                dfc1w = ops.gemm_wgrad(dh, ln2, out=out_w(8))
             del dh
             _, dn2w, dn2b, dx_colsum = ops.layernorm_bwd(dln2, x1, mean2, rstd2, n2w.detach(), dx=dx, dx_bf16=dxb,
                                                          want_dxsum=True)
@@ -368,7 +427,7 @@ class _EncoderFn(torch.autograd.Function):
             datt = ops.gemm_tn(dxb, WprojT, ops.EPI_BF16)
             if wg:
                 dprojw, dprojb = ops.gemm_wgrad(dxb, att, out=out_w(4)), dx_colsum
-            fuse_qkvb = _FUSE_QKV_BIAS and T <= _FUSE_QKV_BIAS_MAXT
+            fuse_qkvb = T <= _FUSE_QKV_BIAS_MAXT
             if wg and fuse_qkvb:
                 dqkv, dqkvb = ops.attention_bwd(qkv, att, datt, lse, B, T, H, want_colsum=True)
             else:
@@ -399,4 +458,6 @@ def encoder(feats, pos, blocks, norm, num_heads, grad_sink=None):
     for blk in blocks:
         bp += block_params(blk)
     train = bool(torch.is_grad_enabled() and any(t.requires_grad for t in (feats, pos, norm.weight, *bp)))
+    # after an optimizer step all 4 L weight operand pairs are stale: one launch re-makes them (instead of 4 L)
+    refresh_weight_operands([bp[l * _BLOCK_PARAMS + j] for l in range(len(blocks)) for j in (2, 4, 8, 10)], train)
     return _EncoderFn.apply(feats, pos, num_heads, norm.eps, grad_sink, train, norm.weight, norm.bias, *bp)

@@ -245,6 +245,14 @@ def cast_weight(w, want=True, want_t=False, rows=None, cols=None, col0=0):
     return dst, dst_t
 
 
+def cast_weights_multi(desc_table, n, total_tiles):
+    """One launch over a device table of cast records (include/p4p_hip.h: p4p_cast_transpose_multi)."""
+    _chk(desc_table, 'desc_table', torch.uint8, 1)
+    if desc_table.numel() != 48 * n:
+        raise RuntimeError('cast_weights_multi: the table must hold n records of 48 bytes')
+    L.call('p4p_cast_transpose_multi', L.ptr(desc_table), int(n), int(total_tiles), _stream())
+
+
 def cast_bf16(x):
     _chk(x, 'x', torch.float32)
     out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)

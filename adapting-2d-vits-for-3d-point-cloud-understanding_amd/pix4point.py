@@ -7,8 +7,6 @@ pix4point.py:30) and ``grad_sink`` (data-parallel gradient hand-off, the referen
 import math
 from typing import Iterator, List, Optional, Tuple, cast
 
-import os
-
 import torch
 import torch.nn as nn
 
@@ -16,7 +14,6 @@ from . import functional as F
 from . import ops
 from .vit import create_model
 
-_TOKEN_STREAM = os.environ.get('P4P_NO_TOKEN_STREAM') is None     # A/B switch: torch.cat assembly instead
 
 
 def farthest_point_sampling(points: torch.Tensor, n_samples: int,
@@ -48,6 +45,11 @@ class P3Embed(nn.Module):
         if in_channels != 3 or layers != 4 or stages != 1:
             raise NotImplementedError('the HIP tokenizer is built for the configuration the reference uses: '
                                       'in_channels=3, layers=4, one stage (sample_ratio=1/scale)')
+        if sample_ratio != 0.25 or scale != 4:
+            # the reference's forward samples N // 4 centroids whatever sample_ratio says (pix4point.py:174: n = int(n // 4));
+            # other one-stage settings (e.g. 0.5 / 2) would build one module tree and run another sampling rate
+            raise NotImplementedError('sample_ratio / scale other than 0.25 / 4: the forward pass samples N // 4 centroids '
+                                      '(reference pix4point.py:174), which only matches these values')
         self.convs = nn.ModuleList()
         self.channel_list = [in_channels]
         conv1 = nn.Sequential(nn.Conv2d(in_channels + 3, width, 1, bias=False), nn.Conv2d(width, width, 1, bias=True),
@@ -111,20 +113,10 @@ class PointViT(nn.Module):
         centers, tok = self.patch_embed.tokens(p, feats_bnc, start_idx)
         p_list = [p, centers]
         x_list = [p.transpose(1, 2) if x is None else x, tok.transpose(1, 2)]
-        if _TOKEN_STREAM and 256 % self.pos_embed[0].weight.shape[0] == 0:
-            h = F.pos_mlp0(centers, self.pos_embed[0].weight, self.pos_embed[0].bias)      # K = 3: not a GEMM
-        else:
-            h = torch.nn.functional.gelu(torch.nn.functional.linear(centers, self.pos_embed[0].weight,
-                                                                    self.pos_embed[0].bias))
-        if _TOKEN_STREAM:
-            # proj / pos_embed[2] write their rows straight into the (B,T,D) streams behind the cls rows (reference :245-252)
-            pos = F.token_stream(h, self.pos_embed[2].weight, self.pos_embed[2].bias, self.cls_pos)
-            feats = F.token_stream(tok, self.proj.weight, self.proj.bias, self.cls_token)
-        else:
-            xt = F.linear(tok, self.proj.weight, self.proj.bias)                               # (B,S,D)
-            pe = F.linear(h, self.pos_embed[2].weight, self.pos_embed[2].bias)
-            pos = torch.cat([self.cls_pos.expand(B, -1, -1), pe], dim=1)
-            feats = torch.cat([self.cls_token.expand(B, -1, -1), xt], dim=1)
+        h = F.pos_mlp0(centers, self.pos_embed[0].weight, self.pos_embed[0].bias)          # K = 3: not a GEMM
+        # proj / pos_embed[2] write their rows straight into the (B,T,D) streams behind the cls rows (reference :245-252)
+        pos = F.token_stream(h, self.pos_embed[2].weight, self.pos_embed[2].bias, self.cls_pos)
+        feats = F.token_stream(tok, self.proj.weight, self.proj.bias, self.cls_token)
         if F._CAPTURE is not None:
             F._CAPTURE['streams'] = dict(centers=centers, tok=tok, h=h, pos=pos, feats=feats)
         feats = F.encoder(feats, pos, list(self.vit_blocks), self.norm, self.vit.num_heads, self.grad_sink)
@@ -139,7 +131,7 @@ class PointViT(nn.Module):
                 kinds.append('cls')
             if 'max' in token_type:
                 kinds.append('max')
-        if _TOKEN_STREAM and kinds and len(set(kinds)) == len(kinds) and x.dtype == torch.float32:
+        if kinds and len(set(kinds)) == len(kinds) and x.dtype == torch.float32:
             return F.global_feat(x, kinds)             # one kernel each way (functional._GlobalFeatFn)
         token_features = x[:, 1:, :]
         cls_feats = []

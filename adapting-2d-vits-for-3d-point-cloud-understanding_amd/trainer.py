@@ -126,12 +126,8 @@ class Pix4PointTrainer:
         t = self.train_config
         self.criterion = nn.CrossEntropyLoss()
         # same update rule, groups and state_dict layout as the reference's optim.AdamW (:104-106); clip + step are three
-        # launches (p4p_amd.optim).  P4P_TORCH_OPTIM=1 keeps stock torch (A/B, debugging).
-        if os.environ.get('P4P_TORCH_OPTIM'):
-            self.optimizer = optim.AdamW(self.model.get_param_groups(), lr=t['learning_rate'], weight_decay=t['weight_decay'],
-                                         fused=True)
-        else:
-            self.optimizer = FusedAdamW(self.model.get_param_groups(), lr=t['learning_rate'], weight_decay=t['weight_decay'])
+        # launches (p4p_amd.optim)
+        self.optimizer = FusedAdamW(self.model.get_param_groups(), lr=t['learning_rate'], weight_decay=t['weight_decay'])
         warm = optim.lr_scheduler.LambdaLR(self.optimizer, lr_lambda=lambda epoch: (epoch + 1) / t['warmup_epochs'])
         cos = optim.lr_scheduler.CosineAnnealingLR(self.optimizer, t['t_max'], eta_min=t['min_lr'])
         self.scheduler = optim.lr_scheduler.SequentialLR(self.optimizer, schedulers=[warm, cos],
@@ -252,6 +248,8 @@ class Pix4PointTrainer:
         self.dataset_config = checkpoint.get('dataset_config', self.dataset_config)
         self._init_model()
         self.model.load_state_dict(checkpoint['model_state_dict'])
+        from .functional import invalidate_operand_caches
+        invalidate_operand_caches(self.model)          # belt and braces: copy_ bumps the version counters anyway
         self._init_optimizer()
         self.optimizer.load_state_dict(checkpoint['optimizer_state_dict'])
         resume = checkpoint.get('resume')              # absent in checkpoints written by the reference

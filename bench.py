@@ -91,10 +91,7 @@ class Stepper:
         broadcast_parameters(self.model)
         self.reducer = build_reducer(self.model, bucket_mb=args.bucket_mb) if distributed else None
         from p4p_amd.optim import FusedAdamW
-        if os.environ.get('P4P_TORCH_OPTIM'):         # A/B: stock torch clip + fused AdamW
-            self.opt = torch.optim.AdamW(self.model.get_param_groups(), lr=5e-4, weight_decay=5e-2, fused=True)
-        else:
-            self.opt = FusedAdamW(self.model.get_param_groups(), lr=5e-4, weight_decay=5e-2)
+        self.opt = FusedAdamW(self.model.get_param_groups(), lr=5e-4, weight_decay=5e-2)
         self.fused_opt = isinstance(self.opt, FusedAdamW)
         self.crit = torch.nn.CrossEntropyLoss()
 

@@ -103,6 +103,10 @@ int p4p_attention_colsum_rows(int B, int T);
 
 /* fp32 master weight [R,C] (row stride ld_src) -> bf16 copies dst [R,C] and dstT [C,R] (either may be NULL). */
 int p4p_cast_transpose_f32_bf16(const float* src, long long ld_src, void* dst, void* dstT, int R, int C, void* stream);
+/* the same for n weights in ONE launch (the per-step refresh of the operand copies after the optimizer step): descs is a DEVICE
+   array of n records {const float* src; bf16* dst; bf16* dstT; long long ld; int R, C; int tile0, tiles_c} (48 B each; tile0 =
+   64 x 64 tiles of the records before it, tiles_c = ceil(C / 64)); every record: R, C, ld % 4 == 0, src 16-B aligned */
+int p4p_cast_transpose_multi(const void* descs, int n, int total_tiles, void* stream);
 int p4p_cast_f32_bf16(const float* src, void* dst, long long n, void* stream);
 /* out[N] = beta*out + column sums of G[M,N] bf16 (autograd of nn.Linear.bias). workspace: p4p_colsum_splits(M)*N f32 */
 int p4p_colsum_bf16(const void* G, float* out, float* workspace, int M, int N, float beta, void* stream);
@@ -168,6 +172,7 @@ int p4p_device_cu_count(void);
 /* experiment switches (tools/gemm_bench.py): tile configuration overrides, 0 = automatic */
 int p4p_set_gemm_variant(int v);
 int p4p_set_wgrad_wide(int v);
+int p4p_set_attention_variant(int v);      /* bit 0: no resident forward / dQ, bit 1: no resident dK/dV, bit 2: no two-pass forward */
 
 /* ---- global feature of PointViT.forward_cls_feat (src/models/pix4point.py:260-271) ----
    fwd: out_max[B,D] = max over tokens 1..T-1 of x[B,T,D] (arg[B,D] = token index of the first maximum), out_cls[B,D] = x[:,0]

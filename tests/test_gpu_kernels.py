@@ -468,3 +468,31 @@ def test_cast_weight_and_transpose_are_exact(R, C, col0, cols):
     assert torch.equal(wb, ref) and torch.equal(wt, ref.t().contiguous())
     only_t = ops.cast_weight(w, False, True, cols=cols, col0=col0)[1]
     assert torch.equal(only_t, ref.t().contiguous())
+
+
+def test_refresh_weight_operands_is_one_exact_launch_for_all_stale_weights():
+    """functional.refresh_weight_operands: the per-step refresh of the encoder's bf16 operand copies (W and W^T of every
+    weight an optimizer step has touched) as ONE launch, in place, exactly torch's cast; clean weights are left alone."""
+    from p4p_amd import functional as F
+    g = torch.Generator().manual_seed(0)
+    ws = [torch.nn.Parameter(torch.randn(*s, generator=g).to(DEV)) for s in ((2304, 768), (768, 768), (3072, 768), (768, 3072),
+                                                                            (192, 64), (260, 132))]
+    assert F.refresh_weight_operands(ws, True) == 6                      # first use: nothing cached yet
+    for w in ws:
+        wb, wt = F._bf16_weights(w, True)
+        assert torch.equal(wb, w.detach().bfloat16()) and torch.equal(wt, w.detach().t().contiguous().bfloat16())
+    assert F.refresh_weight_operands(ws, True) == 0                      # all current
+    ptrs = [F._bf16_weights(w, True)[0].data_ptr() for w in ws]
+    with torch.no_grad():
+        for w in ws[:4]:
+            w.mul_(1.5)                                                  # an "optimizer step" on four of them
+    assert F.refresh_weight_operands(ws, True) == 4
+    for w, ptr in zip(ws, ptrs):
+        wb, wt = F._bf16_weights(w, True)
+        assert wb.data_ptr() == ptr                                      # refreshed IN PLACE
+        assert torch.equal(wb, w.detach().bfloat16()) and torch.equal(wt, w.detach().t().contiguous().bfloat16())
+    # eval first (W only), training later (W^T as well)
+    v = [torch.nn.Parameter(torch.randn(128, 64, generator=g).to(DEV)) for _ in range(3)]
+    assert F.refresh_weight_operands(v, False) == 3 and F._bf16_weights(v[0], False)[1] is None
+    assert F.refresh_weight_operands(v, True) == 3
+    assert torch.equal(F._bf16_weights(v[2], True)[1], v[2].detach().t().contiguous().bfloat16())

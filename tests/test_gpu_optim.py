@@ -143,3 +143,20 @@ def test_grad_scale_is_the_data_parallel_mean_and_nan_norms_propagate():
     ours[2].grad[0] = float('nan')
     norm = opt.step(max_norm=1.0)
     assert bool(torch.isnan(norm)) and all(bool(torch.isnan(p).any()) for p in ours)
+
+
+def test_invalidate_operand_caches_after_a_write_that_bypasses_the_version_counter():
+    """a write through ``.data`` leaves the bf16 operand copies stale (no error); the documented remedy is
+    p4p_amd.invalidate_operand_caches(module)."""
+    import p4p_amd
+    from p4p_amd import functional as F
+    lin = torch.nn.Linear(64, 64).to(DEV)
+    x = torch.randn(8, 64, device=DEV)
+    y0 = F.linear(x, lin.weight, lin.bias)
+    lin.weight.data.mul_(2.0)                                   # bypasses the version counter
+    assert torch.equal(F.linear(x, lin.weight, lin.bias), y0)   # stale operands: the documented hazard
+    assert p4p_amd.invalidate_operand_caches(lin) >= 1
+    y1 = F.linear(x, lin.weight, lin.bias)
+    assert float((y1 - lin.bias - 2 * (y0 - lin.bias)).abs().max()) < 2e-2
+    with pytest.raises(NotImplementedError, match='N // 4'):
+        p4p_amd.P3Embed(in_channels=3, sample_ratio=0.5, scale=2, k=16)
