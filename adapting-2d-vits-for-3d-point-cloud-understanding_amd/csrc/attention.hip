@@ -782,23 +782,98 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dq_q_kernel(AttnParam
 //   dV^T[d][key] += dO^T . P ;  dK^T[d][key] += Q^T . dS
 // ------------------------------------------------------------------------------------------------
 // One Q/dO tile of the dK/dV pass for a wave's 16 keys (RAGGED as in attn_dq_tile; dS unscaled, `scale` goes on dK once).
-template <bool RAGGED>
+// Issue order, pinned with sched_barrier(0) between the sections (hipcc otherwise sinks every LDS read next to its MFMA to
+// save registers: `2 x ds_read_b64_tr -> s_waitcnt -> v_mfma`, 16 times per tile, i.e. 16 exposed LDS latencies that two
+// waves per SIMD cannot hide -- measured ~3,500 cycles per tile for 512 cycles of MFMA):
+//   A  all 16 row fragments (Q and dO rows)            B  16 MFMAs (S, dP) behind counted lgkmcnt waits
+//   C  all 16 transposed fragments (dO^T, Q^T) issued   D  the VALU part (P, dS) runs while they are in flight
+//   E  16 MFMAs (dV, dK)
+// PIN = false leaves the order to hipcc (the streaming kernel: 160 VGPRs, three workgroups per CU; pinned it needs 220 and
+// drops to two, measured 1,252 -> 1,330 us at T = 513); the resident kernel has the registers and pins (-2 %).
+#define PIN_BARRIER() do { if (PIN) __builtin_amdgcn_sched_barrier(0); } while (0)
+template <bool RAGGED, bool PIN = false>
 __device__ __forceinline__ void attn_dkdv_tile(const char* q_lds, const char* do_lds, const float* st, const bf16x8 (&kf)[2],
                                                const bf16x8 (&vf)[2], f32x4 (&dk)[4], f32x4 (&dv)[4], float c, int nvalid,
                                                int lane) {
+    if constexpr (!PIN) {
+        const int g = lane >> 4;
+        f32x4 s[4], dp[4];
+    #pragma unroll
+        for (int q16 = 0; q16 < 4; ++q16) {
+            s[q16] = dp[q16] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!RAGGED || q16 * 16 < nvalid) {
+    #pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    s[q16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(q_lds, q16, ks, lane), kf[ks], s[q16], 0, 0, 0);
+                    dp[q16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(do_lds, q16, ks, lane), vf[ks], dp[q16], 0, 0, 0);
+                }
+            }
+        }
+        f32x4 pr[4];
+    #pragma unroll
+        for (int q16 = 0; q16 < 4; ++q16) {
+            const f32x4 lse4 = *reinterpret_cast<const f32x4*>(st + q16 * 16 + 4 * g);
+            const f32x4 del4 = *reinterpret_cast<const f32x4*>(st + 64 + q16 * 16 + 4 * g);
+    #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[q16][r], c, -lse4[r]));
+                if (RAGGED && q16 * 16 + 4 * g + r >= nvalid) pv = 0.f;
+                pr[q16][r] = pv;
+                s[q16][r] = pv * (dp[q16][r] - del4[r]);
+            }
+        }
+        bf16x8 pb[2] = {pack_pair(pr[0], pr[1]), pack_pair(pr[2], pr[3])};
+        bf16x8 db[2] = {pack_pair(s[0], s[1]), pack_pair(s[2], s[3])};
+    #pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            if (RAGGED && ss * 32 >= nvalid) continue;
+    #pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(do_lds, ss, d, lane), pb[ss], dv[d], 0, 0, 0);
+                dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(q_lds, ss, d, lane), db[ss], dk[d], 0, 0, 0);
+            }
+        }
+    
+        return;
+    }
     const int g = lane >> 4;
     f32x4 s[4], dp[4];
+    bf16x8 fq[4][2], fd[4][2];
+    PIN_BARRIER();
+#pragma unroll
+    for (int q16 = 0; q16 < 4; ++q16) {
+        if (!RAGGED || q16 * 16 < nvalid) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                fq[q16][ks] = frag_rows(q_lds, q16, ks, lane);
+                fd[q16][ks] = frag_rows(do_lds, q16, ks, lane);
+            }
+        }
+    }
+    PIN_BARRIER();
 #pragma unroll
     for (int q16 = 0; q16 < 4; ++q16) {
         s[q16] = dp[q16] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!RAGGED || q16 * 16 < nvalid) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                s[q16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(q_lds, q16, ks, lane), kf[ks], s[q16], 0, 0, 0);
-                dp[q16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(do_lds, q16, ks, lane), vf[ks], dp[q16], 0, 0, 0);
+                s[q16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[q16][ks], kf[ks], s[q16], 0, 0, 0);
+                dp[q16] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[q16][ks], vf[ks], dp[q16], 0, 0, 0);
             }
         }
     }
+    PIN_BARRIER();
+    bf16x8 td[2][4], tq[2][4];
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+        if (RAGGED && ss * 32 >= nvalid) continue;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            td[ss][d] = frag_tr(do_lds, ss, d, lane);
+            tq[ss][d] = frag_tr(q_lds, ss, d, lane);
+        }
+    }
+    PIN_BARRIER();
     f32x4 pr[4];
 #pragma unroll
     for (int q16 = 0; q16 < 4; ++q16) {
@@ -814,15 +889,17 @@ __device__ __forceinline__ void attn_dkdv_tile(const char* q_lds, const char* do
     }
     bf16x8 pb[2] = {pack_pair(pr[0], pr[1]), pack_pair(pr[2], pr[3])};
     bf16x8 db[2] = {pack_pair(s[0], s[1]), pack_pair(s[2], s[3])};
+    PIN_BARRIER();
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
         if (RAGGED && ss * 32 >= nvalid) continue;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(do_lds, ss, d, lane), pb[ss], dv[d], 0, 0, 0);
-            dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(q_lds, ss, d, lane), db[ss], dk[d], 0, 0, 0);
+            dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(td[ss][d], pb[ss], dv[d], 0, 0, 0);
+            dk[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tq[ss][d], db[ss], dk[d], 0, 0, 0);
         }
     }
+    PIN_BARRIER();
 }
 
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
@@ -1036,10 +1113,10 @@ __global__ __launch_bounds__(RES_DKDV_NW * 64, 2) void attn_bwd_dkdv_res_kernel(
 #pragma unroll
         for (int d = 0; d < 4; ++d) dk[d] = dv[d] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int qt = 0; qt < nfull; ++qt)
-            attn_dkdv_tile<false>(qlds + qt * TILE_BYTES, dolds + qt * TILE_BYTES, stats + qt * 128, kf, vf, dk, dv, c, 64, lane);
+            attn_dkdv_tile<false, true>(qlds + qt * TILE_BYTES, dolds + qt * TILE_BYTES, stats + qt * 128, kf, vf, dk, dv, c, 64, lane);
         if (nfull < nqt)
-            attn_dkdv_tile<true>(qlds + nfull * TILE_BYTES, dolds + nfull * TILE_BYTES, stats + nfull * 128, kf, vf, dk, dv, c,
-                                 T - nfull * 64, lane);
+            attn_dkdv_tile<true, true>(qlds + nfull * TILE_BYTES, dolds + nfull * TILE_BYTES, stats + nfull * 128, kf, vf, dk, dv, c,
+                                       T - nfull * 64, lane);
         if (key < T) {
             __bf16* dst = p.out + ((size_t)b * T + key) * ld + h * HD;
 #pragma unroll
