@@ -559,9 +559,13 @@ __device__ __forceinline__ void attn_dq_tile(const char* kt_lds, const char* vt_
                                              int nvalid, int lane) {
     const int g = lane >> 4;
     f32x4 s[4], dp[4];
+    // "row constants as the initial accumulator": the dP chains start from -delta[q], so dS = P (dP - delta) costs no
+    // subtraction (16 VALU per tile); the register quad is the C operand of each chain's first MFMA
+    const f32x4 ndl = {-dl, -dl, -dl, -dl};
 #pragma unroll
     for (int k16 = 0; k16 < 4; ++k16) {
-        s[k16] = dp[k16] = f32x4{0.f, 0.f, 0.f, 0.f};
+        s[k16] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[k16] = ndl;
         if (!RAGGED || k16 * 16 < nvalid) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -576,7 +580,7 @@ __device__ __forceinline__ void attn_dq_tile(const char* kt_lds, const char* vt_
         for (int r = 0; r < 4; ++r) {
             float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[k16][r], c, -lse));
             if (RAGGED && k16 * 16 + 4 * g + r >= nvalid) pr = 0.f;
-            s[k16][r] = pr * (dp[k16][r] - dl);
+            s[k16][r] = pr * dp[k16][r];
         }
     bf16x8 db[2] = {pack_pair(s[0], s[1]), pack_pair(s[2], s[3])};
 #pragma unroll
@@ -655,7 +659,10 @@ __device__ __forceinline__ void attn_dq_tile_q(const char* kt_lds, const char* v
 #pragma unroll
     for (int k16 = 0; k16 < 4; ++k16) {
 #pragma unroll
-        for (int t = 0; t < QT; ++t) s[t][k16] = dp[t][k16] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < QT; ++t) {
+            s[t][k16] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dp[t][k16] = f32x4{-dl[t], -dl[t], -dl[t], -dl[t]};          // dP chains start from -delta[q] (see attn_dq_tile)
+        }
         if (!RAGGED || k16 * 16 < nvalid) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -677,7 +684,7 @@ __device__ __forceinline__ void attn_dq_tile_q(const char* kt_lds, const char* v
             for (int r = 0; r < 4; ++r) {
                 float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][k16][r], c, -lse[t]));
                 if (RAGGED && k16 * 16 + 4 * g + r >= nvalid) pr = 0.f;
-                s[t][k16][r] = pr * (dp[t][k16][r] - dl[t]);
+                s[t][k16][r] = pr * dp[t][k16][r];
             }
         db[t][0] = pack_pair(s[t][0], s[t][1]);
         db[t][1] = pack_pair(s[t][2], s[t][3]);
@@ -800,7 +807,8 @@ __device__ __forceinline__ void attn_dkdv_tile(const char* q_lds, const char* do
         f32x4 s[4], dp[4];
     #pragma unroll
         for (int q16 = 0; q16 < 4; ++q16) {
-            s[q16] = dp[q16] = f32x4{0.f, 0.f, 0.f, 0.f};
+            s[q16] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dp[q16] = *reinterpret_cast<const f32x4*>(st + 64 + q16 * 16 + 4 * g);      // -delta[q]: the chain's initial value
             if (!RAGGED || q16 * 16 < nvalid) {
     #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -813,13 +821,12 @@ __device__ __forceinline__ void attn_dkdv_tile(const char* q_lds, const char* do
     #pragma unroll
         for (int q16 = 0; q16 < 4; ++q16) {
             const f32x4 lse4 = *reinterpret_cast<const f32x4*>(st + q16 * 16 + 4 * g);
-            const f32x4 del4 = *reinterpret_cast<const f32x4*>(st + 64 + q16 * 16 + 4 * g);
     #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[q16][r], c, -lse4[r]));
                 if (RAGGED && q16 * 16 + 4 * g + r >= nvalid) pv = 0.f;
                 pr[q16][r] = pv;
-                s[q16][r] = pv * (dp[q16][r] - del4[r]);
+                s[q16][r] = pv * dp[q16][r];
             }
         }
         bf16x8 pb[2] = {pack_pair(pr[0], pr[1]), pack_pair(pr[2], pr[3])};
@@ -853,7 +860,8 @@ __device__ __forceinline__ void attn_dkdv_tile(const char* q_lds, const char* do
     PIN_BARRIER();
 #pragma unroll
     for (int q16 = 0; q16 < 4; ++q16) {
-        s[q16] = dp[q16] = f32x4{0.f, 0.f, 0.f, 0.f};
+        s[q16] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[q16] = *reinterpret_cast<const f32x4*>(st + 64 + q16 * 16 + 4 * g);          // -delta[q]: the chain's initial value
         if (!RAGGED || q16 * 16 < nvalid) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -878,13 +886,12 @@ __device__ __forceinline__ void attn_dkdv_tile(const char* q_lds, const char* do
 #pragma unroll
     for (int q16 = 0; q16 < 4; ++q16) {
         const f32x4 lse4 = *reinterpret_cast<const f32x4*>(st + q16 * 16 + 4 * g);
-        const f32x4 del4 = *reinterpret_cast<const f32x4*>(st + 64 + q16 * 16 + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[q16][r], c, -lse4[r]));
             if (RAGGED && q16 * 16 + 4 * g + r >= nvalid) pv = 0.f;
             pr[q16][r] = pv;
-            s[q16][r] = pv * (dp[q16][r] - del4[r]);
+            s[q16][r] = pv * dp[q16][r];
         }
     }
     bf16x8 pb[2] = {pack_pair(pr[0], pr[1]), pack_pair(pr[2], pr[3])};
@@ -931,10 +938,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv_kernel(AttnParam
     const bool wave_active = kb * 64 + wave * 16 < T;    // wave-uniform: a wave with no valid key does no math
 
     const int nqt = (T + 63) / 64;
-    // stats for tile qt live in floats [0,64) = lse2, [64,128) = delta of the buffer
+    // stats for tile qt live in floats [0,64) = lse2, [64,128) = -delta of the buffer
     float stat_next = 0.f;
     {
-        if (t < 128) { int qq = (t & 63); qq = qq < T ? qq : T - 1; stat_next = (t < 64 ? lse_b : del_b)[qq]; }
+        if (t < 128) { int qq = (t & 63); qq = qq < T ? qq : T - 1; stat_next = t < 64 ? lse_b[qq] : -del_b[qq]; }
         stage_rows(qbase, ld, 0, T, lds, wave, lane);
         stage_rows(dobase, (size_t)D, 0, T, lds + TILE_BYTES, wave, lane);
         if (t < 128) reinterpret_cast<float*>(lds + 2 * TILE_BYTES)[t] = stat_next;
@@ -951,7 +958,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_bwd_dkdv_kernel(AttnParam
             if (t < 128) {
                 int qq = (qt + 1) * 64 + (t & 63);
                 qq = qq < T ? qq : T - 1;
-                stat_next = (t < 64 ? lse_b : del_b)[qq];
+                stat_next = t < 64 ? lse_b[qq] : -del_b[qq];
             }
             stage_rows(qbase, ld, (qt + 1) * 64, T, nxt, wave, lane);
             stage_rows(dobase, (size_t)D, (qt + 1) * 64, T, nxt + TILE_BYTES, wave, lane);
@@ -1082,7 +1089,7 @@ __global__ __launch_bounds__(RES_DKDV_NW * 64, 2) void attn_bwd_dkdv_res_kernel(
         for (int e = t; e < nqt * 64; e += RES_DKDV_NW * 64) {
             const int qq = e < T ? e : T - 1;
             stats[(e >> 6) * 128 + (e & 63)] = lse_b[qq];
-            stats[(e >> 6) * 128 + 64 + (e & 63)] = del_b[qq];
+            stats[(e >> 6) * 128 + 64 + (e & 63)] = -del_b[qq];          // the dP chains start from -delta (attn_dkdv_tile)
         }
     }
     const int nkt16 = (T + 15) >> 4;
