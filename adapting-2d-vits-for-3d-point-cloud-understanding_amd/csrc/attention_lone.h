@@ -178,3 +178,10 @@ __global__ __launch_bounds__(LONE_NW * 64, 2) void attn_fwd_lone_res_kernel(Attn
         if (lane == 0 && p.lse2) p.lse2[((size_t)b * p.H + h) * T + TL] = M + __builtin_amdgcn_logf(l);
     }
 }
+
+// (A FUSED backward for these shapes -- one workgroup per (b,h): Q, dO, K and a dS^T tile buffer in LDS (138 KB), dK^T / dV^T
+// accumulators in registers for the whole kernel, dS crossing LDS once for dQ, the last row's three gradient rows as
+// matrix-vector MFMAs -- was built in round 2 and verified against fp32 autograd (same errors as the two-kernel path).
+// It needs 5 MFMA products instead of 7 and reads q|k|v, dO once, but at one workgroup per CU its memory phase (194 KB
+// per workgroup at a 1/256 share of HBM: ~180 us over the launch) and its compute phase do not overlap: 500 us against
+// 433 us for attn_bwd_dq_res + attn_bwd_dkdv_res at B = 256, H = 12, T = 257.  Not kept)
