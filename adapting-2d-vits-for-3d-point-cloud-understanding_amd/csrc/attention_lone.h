@@ -89,6 +89,20 @@ __device__ __forceinline__ void lone_fwd_tile(const char* klds, const char* vlds
 
 #define LONE_NW 4          // waves per workgroup: 2 workgroups per CU = 2 waves per SIMD, 256 VGPRs each (64 n + 1 <= 257 scores
                            // per lane stay in registers); the independent MFMA batches of the two passes give the overlap
+// Diagnostic build only (tools/attn_stamps.py compiles attention.hip with -DP4P_LONE_STAMPS into its own library): s_memtime
+// stamps per wave at the phase boundaries, written behind the real lse2 entries.  No stamp exists in the product library.
+#ifdef P4P_LONE_STAMPS
+#define LONE_STAMP(k)                                                                                               \
+    do {                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        const unsigned long long ts_ = __builtin_readcyclecounter();                                                \
+        if (lane == 0) reinterpret_cast<unsigned long long*>(p.lse2 + (size_t)p.B * p.H * p.T)[((size_t)blockIdx.x * LONE_NW + wave) * 8 + (k)] = ts_; \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+    } while (0)
+#else
+#define LONE_STAMP(k) do { } while (0)
+#endif
+
 template <int NT>
 __global__ __launch_bounds__(LONE_NW * 64, 2) void attn_fwd_lone_res_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[2 * NT * TILE_BYTES + NT * LONE_PART_STRIDE * 4];
@@ -101,6 +115,7 @@ __global__ __launch_bounds__(LONE_NW * 64, 2) void attn_fwd_lone_res_kernel(Attn
     char* klds = lds;
     char* vlds = lds + NT * TILE_BYTES;
     float* part = reinterpret_cast<float*>(lds + 2 * NT * TILE_BYTES);
+    LONE_STAMP(0);
 
     {   // stage K and V rows 0 .. 64 NT - 1: 1-KiB pieces of 8 rows
         const int rin = lane >> 3, chunk = (lane & 7) ^ rin;
@@ -129,8 +144,10 @@ __global__ __launch_bounds__(LONE_NW * 64, 2) void attn_fwd_lone_res_kernel(Attn
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) qall[sidx][ks] = *reinterpret_cast<const bf16x8*>(seq + (size_t)q * ld + h * HD + ks * 32 + g * 8);
     }
+    LONE_STAMP(1);
     __builtin_amdgcn_s_waitcnt(0x0F70);          // own LDS-DMA pieces landed (vmcnt(0)), then publish
     __syncthreads();
+    LONE_STAMP(2);
 
 #pragma unroll
     for (int sidx = 0; sidx < NT; ++sidx) {
@@ -147,7 +164,9 @@ __global__ __launch_bounds__(LONE_NW * 64, 2) void attn_fwd_lone_res_kernel(Attn
             *reinterpret_cast<bf16x4*>(dst + d * 16 + 4 * g) = w;
         }
         if (g == 0 && p.lse2) p.lse2[((size_t)b * p.H + h) * T + q] = m + __builtin_amdgcn_logf(l);
+        if (sidx == 0) LONE_STAMP(3);
     }
+    LONE_STAMP(4);
     // ---- the last row as a query: wave w < NT takes key tile w (wave 0 also the last key), partials meet in LDS
     if (wave < NT) {
         const bf16x8 (&qf)[2] = qall[NT];
@@ -162,7 +181,9 @@ __global__ __launch_bounds__(LONE_NW * 64, 2) void attn_fwd_lone_res_kernel(Attn
             for (int d = 0; d < 4; ++d) *reinterpret_cast<f32x4*>(dst + 4 + d * 16 + 4 * g) = o[d];
         }
     }
+    LONE_STAMP(5);
     __syncthreads();
+    LONE_STAMP(6);
     if (wave == NT % LONE_NW) {                  // lane = output dim
         float M = part[0];
 #pragma unroll
@@ -177,7 +198,17 @@ __global__ __launch_bounds__(LONE_NW * 64, 2) void attn_fwd_lone_res_kernel(Attn
         p.out[((size_t)b * T + TL) * D + h * HD + lane] = f2bf(o * (1.0f / l));
         if (lane == 0 && p.lse2) p.lse2[((size_t)b * p.H + h) * T + TL] = M + __builtin_amdgcn_logf(l);
     }
+    LONE_STAMP(7);
 }
+
+// (Where a workgroup of the kernel above spends its life, from a diagnostic build with s_memtime stamps -- tools/attn_stamps.py,
+// B=256, H=12, T=257: 33.9k cycles, of which 13.1k pass until its K / V pieces have landed (the ISSUE of its 128 KB of loads
+// is throttled by the memory system: every workgroup of the chip stages at once at a 1/256 share of HBM), 17.5k in the tiles,
+// 3k in the tail; the two workgroups of a CU overlap these phases only partly.  A PERSISTENT variant that fetches the next
+// (b,h)'s K and V into registers during the compute phase (16 x 16 B per thread, ds_write at the seam) needs 64 more VGPRs than
+// the 256 there are: 71 spills, 185 us against 121 us.  Not kept.  The way to overlap the two phases inside one workgroup is a
+// second LDS buffer filled by LDS-DMA, which needs inline-asm fragment reads first (hipcc parks every builtin ds_read behind
+// vmcnt(0) while a DMA is outstanding): DESIGN.md section 9.)
 
 // (A FUSED backward for these shapes -- one workgroup per (b,h): Q, dO, K and a dS^T tile buffer in LDS (138 KB), dK^T / dV^T
 // accumulators in registers for the whole kernel, dS crossing LDS once for dQ, the last row's three gradient rows as
