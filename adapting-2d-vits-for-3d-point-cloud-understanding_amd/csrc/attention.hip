@@ -420,14 +420,40 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_q_kernel(AttnParams p
         }
     };
     const int nkt = (T + 63) / 64, nfull = T / 64;
+#ifdef P4P_LONE_STAMPS      // diagnostic build (tools/attn_stamps.py): cycles spent waiting at the stage fence vs in the tile math
+    unsigned long long t_wait = 0, t_math = 0, t_start = __builtin_readcyclecounter();
+#endif
     stage_any(0, lds);
     const bool wave_active = q0 < T;
     for (int kt = 0; kt < nfull; ++kt) {
+#ifdef P4P_LONE_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long ta = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         STAGE_FENCE();
+#ifdef P4P_LONE_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long tb = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         const char* cur = lds + (kt & 1) * 2 * TILE_BYTES;
         if (kt + 1 < nkt) stage_any(kt + 1, lds + ((kt + 1) & 1) * 2 * TILE_BYTES);
         if (wave_active) attn_fwd_tile_q<false, QT>(cur, cur + TILE_BYTES, qf, o, m, lsum, c, kt * 64, T, lane);
+#ifdef P4P_LONE_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long tc = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+        t_wait += tb - ta;
+        t_math += tc - tb;
+#endif
     }
+#ifdef P4P_LONE_STAMPS
+    if (lane == 0 && p.lse2) {
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.lse2 + (size_t)p.B * p.H * p.T) + ((size_t)blockIdx.x * 4 + wave) * 4;
+        dst[0] = t_wait; dst[1] = t_math; dst[2] = __builtin_readcyclecounter() - t_start; dst[3] = wave_active;
+    }
+#endif
     if (nfull < nkt) {
         STAGE_FENCE();
         const char* cur = lds + (nfull & 1) * 2 * TILE_BYTES;

@@ -6,12 +6,17 @@
 // (coalesced HBM read, conflict-free LDS reads).  Each wave owns one centroid at a time:
 //   * every lane computes the exact squared distance to 16 points of the current 1024-point chunk
 //     and keeps them as u64 keys (float_bits(d) << 32) | index  -- d >= 0, so u64 order == (d, index)
-//     lexicographic order, which IS the tie rule (lowest index first);
-//   * the k best keys seen so far live one per lane (lanes 0..k-1); `tau` is the largest of them;
-//   * selection: wave-min of the chunk (DPP), stop the chunk as soon as min >= tau, otherwise the
-//     owning lane retires that key (ballot picks the owner) and it replaces the lane holding tau.
-//     The first chunk costs k+1 rounds; later chunks stop after the few keys that beat tau.
-//   * the k survivors are ranked by counting smaller keys (k readlanes) and written sorted.
+//     lexicographic order, which IS the tie rule (lowest index first); while it does so it tracks its two
+//     smallest keys (min1, min2);
+//   * the k best keys so far live SORTED in lanes 0..k-1; tau = the k-th of them (+inf until there are k);
+//   * selection = repeated extract-min: wave-min of the lanes' min1 (two 32-bit DPP reductions: distance bits,
+//     then index among the ties), stop the chunk as soon as it is >= tau; the winning key is inserted into the
+//     sorted list (a ballot count gives the position, one wave_shr DPP shifts the tail) and its lane advances to
+//     min2.  A lane that loses both tracked keys rescans its 16 (it retires keys in ascending order, so the
+//     survivors are simply the keys above the last one it gave away) -- rare: ~2 lanes per centroid.
+//     Round 1 re-scanned all 16 keys of every lane and re-derived tau with a second wave reduction in EVERY
+//     round (~150 instructions per round, 2,700 per centroid at N = 1024, k = 16); this form needs ~50 per round
+//     and no ranking pass at the end: the list is already in output order.
 //
 // Order contract (oracle/pix4point_oracle.py: knn_indices): ascending ((dx*dx+dy*dy)+dz*dz) in
 // unfused fp32, ties to the lowest point index, int32 output (pix4point.py:89).
@@ -20,6 +25,31 @@
 #define KNN_THREADS 256
 #define KNN_WAVES 4
 #define KNN_CHUNK_P 16                    // keys per lane per chunk -> 1024 points per chunk
+
+__device__ __forceinline__ u32 wave_min_u32(u32 v) {
+    u32 o;
+    o = dpp_u32<0xB1>(v);  v = o < v ? o : v;
+    o = dpp_u32<0x4E>(v);  v = o < v ? o : v;
+    o = dpp_u32<0x141>(v); v = o < v ? o : v;
+    o = dpp_u32<0x140>(v); v = o < v ? o : v;
+    const u32 a = (u32)__builtin_amdgcn_readlane((int)v, 0), b = (u32)__builtin_amdgcn_readlane((int)v, 16);
+    const u32 c = (u32)__builtin_amdgcn_readlane((int)v, 32), d = (u32)__builtin_amdgcn_readlane((int)v, 48);
+    const u32 ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+// minimum of the lanes' keys in (distance bits, index) order: the index only among the lanes that hold the minimum distance
+__device__ __forceinline__ u64 wave_min_key(u64 v) {
+    const u32 hi = (u32)(v >> 32);
+    const u32 mh = wave_min_u32(hi);
+    const u32 ml = wave_min_u32(hi == mh ? (u32)v : 0xFFFFFFFFu);
+    return ((u64)mh << 32) | ml;
+}
+// lane l receives lane l-1's value (lane 0 keeps its own): DPP wave_shr:1
+__device__ __forceinline__ u64 wave_shr1_u64(u64 v) {
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp((int)(u32)v, (int)(u32)v, 0x138, 0xF, 0xF, false);
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp((int)(u32)(v >> 32), (int)(u32)(v >> 32), 0x138, 0xF, 0xF, false);
+    return ((u64)hi << 32) | lo;
+}
 
 __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float* __restrict__ points,
                                                            const float* __restrict__ centroids,
@@ -41,51 +71,64 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_kernel(const float* __restric
 
     const int s_begin = blockIdx.x * cpb;
     const int s_end = min(S, s_begin + cpb);
-    const u64 INF = ~0ull;
+    const u64 INF = ~0ull;          // no key
+    const u64 UNK = ~0ull - 1;      // "second smallest not tracked any more": a real key is always below (index < 2^32 - 2)
 
     for (int s = s_begin + wave; s < s_end; s += KNN_WAVES) {
         const float* c = centroids + ((size_t)b * S + s) * 3;
         const float cx = c[0], cy = c[1], cz = c[2];
-        u64 best = INF;          // lanes [0,k): one of the k best keys so far
-        u64 tau = INF;           // max over best[0..k)
+        u64 best = INF;          // lanes [0,k): the k best keys so far, ascending; INF = empty slot (and every lane >= k)
+        u64 tau = INF;           // the k-th best once k keys are held
+        int cnt = 0;             // keys held (wave-uniform)
         for (int base = 0; base < N; base += 64 * KNN_CHUNK_P) {
             u64 key[KNN_CHUNK_P];
-            u64 lmin = INF;
+            u64 min1 = INF, min2 = INF;
 #pragma unroll
             for (int j = 0; j < KNN_CHUNK_P; ++j) {
                 int i = base + j * 64 + lane;
                 int ic = i < N ? i : N - 1;
                 float d = sqdist3(sx[ic], sy[ic], sz[ic], cx, cy, cz);
                 u64 kk = ((u64)__builtin_bit_cast(u32, d) << 32) | (u32)i;
-                key[j] = i < N ? kk : INF;
-                lmin = key[j] < lmin ? key[j] : lmin;
+                kk = i < N ? kk : INF;
+                key[j] = kk;
+                const u64 hi2 = kk < min1 ? min1 : kk;          // the larger of (kk, min1)
+                min1 = kk < min1 ? kk : min1;
+                min2 = hi2 < min2 ? hi2 : min2;
             }
-            // at most k+1 rounds in the first chunk, far fewer later; bounded for safety
+            u64 floor_key = 0;       // this lane has given away every key below floor_key
+            // at most k rounds in the first chunk, far fewer later; bounded for safety
             for (int round = 0; round < 64 * KNN_CHUNK_P; ++round) {
-                u64 m = wave_min_u64(lmin);
+                const u64 m = wave_min_key(min1);
                 if (m >= tau) break;                           // wave-uniform (also covers m == INF)
-                if (lmin == m) {                               // exactly one lane: keys are unique
-                    lmin = INF;
+                // ---- insert m into the sorted list: position = number of held keys below it
+                const int pos = __builtin_popcountll(__ballot(best < m));
+                const u64 shifted = wave_shr1_u64(best);
+                best = lane < pos ? best : (lane == pos ? m : shifted);
+                best = lane < k ? best : INF;
+                cnt = cnt < k ? cnt + 1 : k;
+                tau = cnt == k ? readlane_u64(best, k - 1) : INF;
+                // ---- the owning lane (keys are unique) moves on to its next key
+                const bool owner = min1 == m;
+                bool rescan = false;
+                if (owner) {
+                    floor_key = m + 1;
+                    if (min2 == UNK) rescan = true;
+                    else { min1 = min2; min2 = min2 == INF ? INF : UNK; }
+                }
+                if (__any(rescan)) {                            // rare: the lane lost both tracked keys
+                    u64 n1 = INF, n2 = INF;
 #pragma unroll
                     for (int j = 0; j < KNN_CHUNK_P; ++j) {
-                        key[j] = key[j] == m ? INF : key[j];
-                        lmin = key[j] < lmin ? key[j] : lmin;
+                        const u64 kk = key[j] >= floor_key ? key[j] : INF;
+                        const u64 hi2 = kk < n1 ? n1 : kk;
+                        n1 = kk < n1 ? kk : n1;
+                        n2 = hi2 < n2 ? hi2 : n2;
                     }
+                    if (rescan) { min1 = n1; min2 = n2; }
                 }
-                // replace the first lane (< k) whose best equals tau
-                u64 holders = __ballot(lane < k && best == tau);
-                int victim = __builtin_ctzll(holders);
-                if (lane == victim) best = m;
-                tau = wave_max_u64(lane < k ? best : 0ull);
             }
         }
-        // rank the k survivors; keys are distinct so ranks are a permutation of 0..k-1
-        int rank = 0;
-        for (int q = 0; q < k; ++q) {
-            u64 o = readlane_u64(best, q);
-            rank += o < best ? 1 : 0;
-        }
-        if (lane < k) out_idx[((size_t)b * S + s) * k + rank] = (int32_t)(u32)best;
+        if (lane < k) out_idx[((size_t)b * S + s) * k + lane] = (int32_t)(u32)best;
     }
 }
 

@@ -32,3 +32,21 @@ for k, n in enumerate(names):
     print(f'  {n:28s} {float(rel[..., k].mean()):10.0f}   (wave 0: {float(rel[:, 0, k].mean()):8.0f}, wave 3: {float(rel[:, 3, k].mean()):8.0f})')
 life = (raw[..., 7].max(dim=1).values - raw[..., 0].min(dim=1).values)
 print('workgroup lifetime mean', float(life.mean()), 'ticks; kernel span', float(raw[..., 7].max() - raw[..., 0].min()), 'ticks')
+
+# ---- streaming forward (T = 513): wait at the stage fence vs tile math, per wave
+B, T, H = 256, 513, 12
+qkv = torch.randn(B * T, 3 * D, generator=g).to(torch.bfloat16).cuda()
+out = torch.empty(B * T, D, dtype=torch.bfloat16, device='cuda')
+nblk = (T + 127) // 128
+nwg = ((B * H + 7) // 8) * 8 * nblk
+lse = torch.zeros(B * H * T + 2 * nwg * 4 * 4 + 8, dtype=torch.float32, device='cuda')
+for _ in range(3):
+    assert lib.p4p_attention_fwd(ptr(qkv), ptr(out), ptr(lse), B, T, H, D, ctypes.c_float(0.125), st) == 0
+torch.cuda.synchronize()
+raw = lse[B * H * T:B * H * T + 2 * nwg * 4 * 4].view(torch.int64).view(nwg * 4, 4).cpu().double()
+act = raw[:, 3] > 0
+print(f'streaming forward T={T}: active waves {int(act.sum())} of {raw.shape[0]}')
+for name, sel in (('active waves', act), ('waves without a valid query', ~act & (raw[:, 2] > 0))):
+    r = raw[sel]
+    if len(r):
+        print(f'  {name:30s} fence wait {float(r[:, 0].mean()):8.0f}  tile math {float(r[:, 1].mean()):8.0f}  whole loop+prologue {float(r[:, 2].mean()):8.0f} cycles')
