@@ -28,9 +28,13 @@
 // The tiles are staged with LDS-DMA (global_load_lds), which is tracked by vmcnt, not by the workgroup fence inside
 // __syncthreads(): every wave drains its own DMAs explicitly before the barrier, so that after the barrier all
 // pieces of the tile have landed whatever the wave does next (a wave with no valid row skips the math entirely).
+// The wait is vmcnt(0) AND lgkmcnt(0) (0x0070): with an explicit vmcnt-only wait in front, hipcc dropped the fence's own
+// lgkmcnt(0) in attn_bwd_dkdv_kernel, and the ds_write of the next tile's lse / -delta could then still be in its SIMD's
+// LDS queue when a wave of another SIMD read it right after the barrier (one 16-key dK tile off by ~1e-3 in about one
+// launch in ten at B*H = 1536, T = 513; found by the bitwise-reproducibility test).
 #define STAGE_FENCE()                          \
     do {                                       \
-        __builtin_amdgcn_s_waitcnt(0x0F70);    \
+        __builtin_amdgcn_s_waitcnt(0x0070);    \
         __syncthreads();                       \
     } while (0)
 
@@ -520,7 +524,7 @@ __global__ __launch_bounds__(RES_NW * 64, 4) void attn_fwd_res_kernel(AttnParams
         for (int ks = 0; ks < 2; ++ks)
             qf[s][ks] = *reinterpret_cast<const bf16x8*>(seq + (size_t)q * ld + h * HD + ks * 32 + g * 8);
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);          // own LDS-DMA pieces landed (vmcnt(0)), then publish
+    __builtin_amdgcn_s_waitcnt(0x0070);          // own LDS-DMA pieces landed (vmcnt(0)), then publish
     __syncthreads();
 
     const int nkt = (T + 63) / 64, nfull = T / 64;
@@ -1043,7 +1047,7 @@ __global__ __launch_bounds__(RES_NW * 64, 4) void attn_bwd_dq_res_kernel(AttnPar
     char* klds = lds;
     char* vlds = lds + RES_ROWS * 128;
     res_stage_pair<RES_NW>(seq + D + h * HD, ld, seq + 2 * D + h * HD, ld, klds, vlds, T, wave, lane);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_waitcnt(0x0070);
     __syncthreads();
 
     const int nqt = (T + 15) >> 4, nkt = (T + 63) / 64, nfull = T / 64;
@@ -1136,7 +1140,7 @@ __global__ __launch_bounds__(RES_DKDV_NW * 64, 2) void attn_bwd_dkdv_res_kernel(
     };
     bf16x8 kf[2], vf[2], kfn[2], vfn[2];
     load_kv(w0, kf, vf);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_s_waitcnt(0x0070);
     __syncthreads();
 
     for (int kt = w0; kt < nkt16; kt += RES_DKDV_NW) {

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(LONE_NW * 64, 2) void attn_fwd_lone_res_kernel(Attn
         for (int ks = 0; ks < 2; ++ks) qall[sidx][ks] = *reinterpret_cast<const bf16x8*>(seq + (size_t)q * ld + h * HD + ks * 32 + g * 8);
     }
     LONE_STAMP(1);
-    __builtin_amdgcn_s_waitcnt(0x0F70);          // own LDS-DMA pieces landed (vmcnt(0)), then publish
+    __builtin_amdgcn_s_waitcnt(0x0070);          // own LDS-DMA pieces landed (vmcnt(0)), then publish
     __syncthreads();
     LONE_STAMP(2);
 
