@@ -447,6 +447,41 @@ def test_full_model_reference_shape_train_step_runs():
     assert torch.equal(frozen, m.blocks[3].mlp.fc1.weight)
 
 
+def test_full_size_train_step_is_bitwise_reproducible():
+    """BASELINE config 4 at the benchmark's size (B=128, N=2048, xyz + height, ViT-B frozen): no kernel on this path uses
+    atomics and every split reduction is summed in a fixed order, so repeated steps from the same state agree bit for bit
+    (every dropout / DropPath rate 0: their masks are the only intended randomness)."""
+    B, N = 128, 2048
+    torch.manual_seed(0)
+    m = PA.AdaptPointFormer(num_classes=15, in_channels=4, vit_name='vit_base_patch16_224', pretrained=False, dropout_rate=0.0,
+                            dropout_path_rate=0.0).to(DEV).train()
+    for mod in m.modules():                                 # the head's Dropout(0.4) layers (apf.py:222-223)
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    xyz = A.synthetic_clouds(B, N, seed=5)
+    pts = torch.cat([xyz, xyz[:, :, 1:2] - xyz[:, :, 1:2].min(dim=1, keepdim=True).values], dim=-1).contiguous().to(DEV)
+    start = torch.randint(0, N, (B,), generator=torch.Generator().manual_seed(6)).to(DEV)
+    labels = (torch.arange(B) % 15).to(DEV)
+    bufs = [b.detach().clone() for b in m.buffers()]
+
+    def run():
+        for b, v in zip(m.buffers(), bufs):
+            b.copy_(v)
+        m.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(m(pts, start), labels, label_smoothing=0.3)
+        loss.backward()
+        return loss.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    l1, g1 = run()
+    assert bool(torch.isfinite(l1)) and len(g1) > 20
+    for r in range(4):
+        l2, g2 = run()
+        assert torch.equal(l1, l2), f'loss differs in run {r}'
+        for n in g1:
+            assert bool(torch.isfinite(g1[n]).all()), n
+            assert torch.equal(g1[n], g2[n]), f'{n} differs in run {r}'
+
+
 # --------------------------------------------------------------------------------------------- in_channels = 4 (xyz + height)
 # the reference's shipped configuration (train_apf.py:5,29); fixtures: tests/golden/make_golden_apf_height.py
 def _lexsorted_c(nb):
