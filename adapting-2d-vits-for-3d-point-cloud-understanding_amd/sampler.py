@@ -1,0 +1,85 @@
+"""Drop-in for the reference's ``src/data/sampler.py`` (the names ``src/data/__init__.py`` exports and the ones
+``src/models/apf.py`` / ``src/data/scanobjectnn.py`` import), on the HIP index kernels: no (B,S,N) distance matrix, no Python
+loop over the samples, no CPU fallback.
+
+The reference keeps four implementations of one function (``fps_sampling_with_knn``, ``_optimized``, ``_topk``,
+``_cuda_optimized``: sampler.py:199-227, 317-345, 455-484, 528-547) that differ in how they vectorise the same arithmetic:
+farthest-point sampling on ``sum((p - c)**2)`` from a random start, then the k nearest points of every sample by the same
+distance, ascending.  Here all four names are the one kernel path (``p4p_fps_f32`` + ``p4p_knn_f32`` + ``p4p_group_gather_f32``),
+whose order contract is exactly that arithmetic: ``((dx*dx + dy*dy) + dz*dz)`` in unfused fp32, ties to the lowest index
+(torch.topk leaves ties unspecified).
+
+Additive: ``start_idx`` (the reference draws the first sample unseeded, sampler.py:120); restriction: coordinates only, D == 3
+(the reference takes the distance over all D columns; the kernels are xyz kernels and refuse anything else loudly).
+"""
+from typing import Optional, Tuple, Union
+
+import torch
+
+from . import ops
+from .apf import furthest_point_sample, index_points, knn_point          # sampler.py:4-30, 64-94  # noqa: F401
+
+
+def fps(data: torch.Tensor, number: int, start_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sampler.py:33-45: (B,N,C) -> the ``number`` farthest-point samples (B,number,C), sampled on the first three columns."""
+    idx = furthest_point_sample(data[:, :, :3].contiguous().float(), number, start_idx)
+    return torch.gather(data, 1, idx.unsqueeze(-1).expand(-1, -1, data.shape[-1]))
+
+
+def _farthest_point_sampling(points: torch.Tensor, n_samples: int, start_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sampler.py:98-143 (and its three variants): int64 (B, min(n_samples, N))."""
+    if points.dim() != 3 or points.shape[-1] != 3:
+        raise RuntimeError(f'sampler: the HIP index kernels take xyz clouds (B,N,3), got {tuple(points.shape)}')
+    return ops.fps(points.contiguous().float(), n_samples, start_idx)
+
+
+def _get_knn_points(points: torch.Tensor, centroids: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """sampler.py:146-196: points (B,N,3), centroid INDICES (B,S) -> (grouped points (B,S,k,3), neighbour indices (B,S,k)).
+    The reference returns indices into the flattened (B*N) array (it adds ``b*N``, sampler.py:185); so does this."""
+    if points.dim() != 3 or points.shape[-1] != 3:
+        raise RuntimeError(f'sampler: the HIP index kernels take xyz clouds (B,N,3), got {tuple(points.shape)}')
+    B, N, _ = points.shape
+    if k > N:
+        raise RuntimeError(f'sampler: k={k} exceeds N={N}')          # torch.topk raises here too
+    pts = points.contiguous().float()
+    cen = torch.gather(pts, 1, centroids.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    idx = ops.knn(pts, cen, k)
+    grouped = ops.group_gather(pts, idx)
+    return grouped, idx.long() + torch.arange(B, device=points.device).view(B, 1, 1) * N
+
+
+def fps_sampling_with_knn(points: torch.Tensor, n_samples: int, k: int, return_centroids: bool = False,
+                          start_idx: Optional[torch.Tensor] = None) -> Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
+    """sampler.py:199-227: (B,N,3) or (N,3) -> grouped points (B,S,k,3) [, centroid indices (B,S) int64]."""
+    if points.dim() == 2:
+        points = points.unsqueeze(0)
+    centroid_indices = _farthest_point_sampling(points, n_samples, start_idx)
+    grouped_points, _ = _get_knn_points(points, centroid_indices, k)
+    if return_centroids:
+        return grouped_points, centroid_indices
+    return grouped_points
+
+
+# the reference's alternative vectorisations of the same function (sampler.py:317-345, 455-484, 528-547).  Its
+# ``_cuda_optimized`` form takes cdist(...)**2 (sqrt, then square) for N > 1000 on a GPU (sampler.py:510-512), which can pick a
+# different sample at a near tie than its three siblings; this build keeps the exact distance under all four names.
+fps_sampling_with_knn_optimized = fps_sampling_with_knn
+fps_sampling_with_knn_topk = fps_sampling_with_knn
+fps_sampling_with_knn_cuda_optimized = fps_sampling_with_knn
+
+
+def benchmark_fps_implementations(points: torch.Tensor, n_samples: int, k: int, num_runs: int = 10) -> None:
+    """sampler.py:549-601 prints the times of its implementations; here there is one, timed with device events."""
+    if points.dim() == 2:
+        points = points.unsqueeze(0)
+    print(f"Benchmarking FPS on {tuple(points.shape)} with {n_samples} samples, k={k}")
+    print(f"Device: {points.device}")
+    start = torch.zeros(points.shape[0], dtype=torch.long, device=points.device)
+    fps_sampling_with_knn(points, n_samples, k, start_idx=start)
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(num_runs):
+        fps_sampling_with_knn(points, n_samples, k, start_idx=start)
+    t1.record()
+    torch.cuda.synchronize(points.device)
+    print(f"HIP implementation (all four names): {t0.elapsed_time(t1) * 1e-3 / num_runs:.6f}s")
