@@ -9,6 +9,8 @@ warm-up from ``warmup_lr_init`` over ``warmup_t`` epochs, then one cosine cycle 
 """
 import csv
 import math
+import os
+import time
 
 import torch
 import torch.nn as nn
@@ -39,11 +41,34 @@ class CosineWarmupLR:
             g['lr'] = self.lr_at(epoch, b)
 
 
+def save_configs(model_config: dict, dataset_config: dict, train_config: dict, output_dir: str, device: str) -> str:
+    """The experiment record the reference's APF trainer leaves in its output directory before anything else
+    (src/train/train_utils.py:4-46, called at apf_trainer.py:53): ``experiment_config_<timestamp>.txt`` with one
+    ``key: value`` line per entry of the three dicts, then device / directory / timestamp.  Returns the path."""
+    stamp = time.strftime('%Y-%m-%d_%H-%M-%S')
+    path = os.path.join(output_dir, f'experiment_config_{stamp}.txt')
+    sections = (('MODEL', model_config), ('DATASET', dataset_config), ('TRAINING', train_config))
+    lines = ['======== EXPERIMENT CONFIGURATION ========', '']
+    for title, cfg in sections:
+        lines.append(f'== {title} CONFIGURATION ==')
+        lines += [f'{k}: {v}' for k, v in cfg.items()]
+        lines.append('')
+    lines += ['== ENVIRONMENT ==', f'Device: {device}', f'Output directory: {output_dir}', f'Timestamp: {stamp}']
+    with open(path, 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    print(f'Configuration saved to {path}')
+    return path
+
+
 class APFTrainer(Pix4PointTrainer):
     """Trainer for AdaptPointFormer (reference apf_trainer.py:20-345); the epoch loops are the shared ones."""
 
     def __init__(self, model_config: dict, dataset_config: dict, train_config: dict, device: str = "cpu",
                  output_dir: str = "./output") -> None:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0:      # reference :49-53
+            os.makedirs(output_dir, exist_ok=True)
+            save_configs(model_config, dataset_config, train_config, output_dir, device if device else 'cuda')
         super().__init__(model_config, dataset_config, train_config, device, output_dir)
 
     # ---- reference :64-82
