@@ -44,12 +44,15 @@ struct T3Frags {
 // during the math phases and the VALU during the store phases (K = 64 runs of the fused epilogues moved their bytes
 // at 2.8-3.8 TB/s, and the epilogue time simply added to the MFMA loop).  Here the stores of slab j drain while
 // slab j+1 is computed, and the loads a slab needs (residual / gelu') are issued one slab ahead.
-//   fp32 residual output: registers -> global directly (16 B per lane; the 4 column blocks i of a row complete
-//     256 contiguous bytes);  bf16 outputs: a wave-private 16 x 64 LDS slab turns the 8-B accumulator pieces
-//     into 16-B stores of whole 128-B row segments.
+//   fp32 residual output: LDS_FREE (gemm_tn4_kernel): (acc + bias) goes through the wave-private slab as well and leaves as
+//     whole 256-B row segments, 4 rows per store instruction, the residual(s) read the same way and added on the row side
+//     (same association, bit-identical; round 2: proj 150.7 -> 140.0 us, fc2 302.2 -> 285.9 at M = 65,792, 275 -> 254 and
+//     575 -> 548 at M = 131,328 against the accumulator-layout form, whose instructions touch 16 rows x 64 B each);
+//     otherwise registers -> global directly.  bf16 outputs: a wave-private 16 x 64 LDS slab turns the 8-B accumulator
+//     pieces into 16-B stores of whole 128-B row segments.
 // The caller guarantees that no wave reads the operand ring any more (the slabs live at `lds`, 4.5 KiB per wave).
 // =================================================================================================
-template <int EPI>
+template <int EPI, bool LDS_FREE = false>
 __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 (&acc)[4][8], char* lds, int tm, int m0,
                                                      int n0, int wm, int wn, int wave, int lane) {
     const int li = lane & 15, g = lane >> 4;
@@ -68,6 +71,51 @@ __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 
         const float* rsrc2 = p.rowgrp ? p.rowgrp + (size_t)colbase + g * 4 : nullptr;
         float* dst = (float*)p.out + (size_t)colbase + g * 4;
         auto row_of = [&](int j) { int m = rowbase + j * 16 + li; return m < p.M ? m : p.M - 1; };
+        if constexpr (LDS_FREE) {
+            // rows through the wave's LDS slab: every global access (residual reads, output stores) is 4 whole 256-B row
+            // segments per instruction instead of 16 rows x 64 B; the sums keep their association ((acc + bias) + resid)
+            constexpr int FS = 272;                          // 256-B rows + 16
+            char* fslab = lds + wave * 4608;
+            const int rr = lane >> 4, cc = lane & 15;
+            const float* q1 = p.resid ? p.resid + (size_t)colbase + cc * 4 : nullptr;
+            const float* q2 = p.rowgrp ? p.rowgrp + (size_t)colbase + cc * 4 : nullptr;
+            auto row_at = [&](int j, int h) { int m = rowbase + j * 16 + h * 4 + rr; return m < p.M ? m : p.M - 1; };
+            f32x4 nxt[4];
+            auto fetch = [&](int j) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    nxt[h] = q1 ? *reinterpret_cast<const f32x4*>(q1 + (size_t)row_at(j, h) * p.N) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (q2) nxt[h] += *reinterpret_cast<const f32x4*>(q2 + (size_t)row_at(j, h) * p.N);
+                }
+            };
+            fetch(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f32x4 cur[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) cur[h] = nxt[h];
+                if (j + 1 < 8 && q1) fetch(j + 1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<f32x4*>(fslab + li * FS + i * 64 + g * 16) = acc[i][j] + bias4[i];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int m = rowbase + j * 16 + h * 4 + rr;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(fslab + (h * 4 + rr) * FS + cc * 16) + cur[h];
+                    if (m < p.M) {
+                        const size_t orow = p.group > 1 ? (size_t)m + m / p.group + 1 : (size_t)m;
+                        *reinterpret_cast<f32x4*>((float*)p.out + orow * p.N + colbase + cc * 4) = v;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            return;
+        }
         f32x4 rnext[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -125,23 +173,45 @@ __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 
 #pragma unroll
     for (int i = 0; i < 4; ++i) csum_all[i] = csq_all[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    bf16x4 hnext[4];                                        // dGELU: gelu'(h) of the next slab, in accumulator layout
+    // dGELU: gelu'(h) of the next slab is fetched one slab ahead.  LDS_FREE: as whole 128-B row segments (8 rows per load
+    // instruction) that reach the accumulator layout through the idle `pre` half of the slab; otherwise straight in the
+    // accumulator layout (16 rows x 32 B per instruction)
+    constexpr bool HROWS = LDS_FREE && EPI == EPI_BF16_DGELU;
+    bf16x4 hnext[4];
+    u32x4 hrows[2];
     const __bf16* hsrc = EPI == EPI_BF16_DGELU ? p.pre + (size_t)colbase + g * 4 : nullptr;
+    const __bf16* hsrc_r = EPI == EPI_BF16_DGELU ? p.pre + (size_t)colbase + (lane & 7) * 8 : nullptr;
     auto hrow = [&](int j) { int m = rowbase + j * 16 + li; return m < p.M ? m : p.M - 1; };
-    if (EPI == EPI_BF16_DGELU) {
+    auto hfetch = [&](int j) {
+        if constexpr (HROWS) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) hnext[i] = *reinterpret_cast<const bf16x4*>(hsrc + (size_t)hrow(0) * p.N + i * 16);
-    }
+            for (int h2 = 0; h2 < 2; ++h2) {
+                int m = rowbase + j * 16 + h2 * 8 + (lane >> 3);
+                m = m < p.M ? m : p.M - 1;
+                hrows[h2] = *reinterpret_cast<const u32x4*>(hsrc_r + (size_t)m * p.N);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hnext[i] = *reinterpret_cast<const bf16x4*>(hsrc + (size_t)hrow(j) * p.N + i * 16);
+        }
+    };
+    if (EPI == EPI_BF16_DGELU) hfetch(0);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         bf16x4 hcur[4];
         if (EPI == EPI_BF16_DGELU) {
+            if constexpr (HROWS) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) hcur[i] = hnext[i];
-            if (j + 1 < 8) {
+                for (int h2 = 0; h2 < 2; ++h2)
+                    *reinterpret_cast<u32x4*>(slab + SLAB_BYTES + (h2 * 8 + (lane >> 3)) * SLAB_STRIDE + (lane & 7) * 16) = hrows[h2];
+                wave_lds_sync();
 #pragma unroll
-                for (int i = 0; i < 4; ++i) hnext[i] = *reinterpret_cast<const bf16x4*>(hsrc + (size_t)hrow(j + 1) * p.N + i * 16);
+                for (int i = 0; i < 4; ++i) hcur[i] = *reinterpret_cast<const bf16x4*>(slab + SLAB_BYTES + wr_off + i * 32);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hcur[i] = hnext[i];
             }
+            if (j + 1 < 8) hfetch(j + 1);
         }
         const bool row_ok = rowbase + j * 16 + li < p.M;
 #pragma unroll

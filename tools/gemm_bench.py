@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import p4p_amd
 from p4p_amd import ops, _lib
 dev = 'cuda'
+if os.environ.get('P4P_DEBUG_LIB'):          # A/B of two builds of the library in one gpurun call
+    _lib.LIB_PATH = os.path.abspath(os.environ['P4P_DEBUG_LIB'])
 lib = _lib.lib()
 M, D = int(os.environ.get("GB_M", 256 * 257)), 768
 shapes = {'qkv': (M, 3 * D, D, ops.EPI_BF16), 'proj': (M, D, D, ops.EPI_F32_RESID), 'fc1': (M, 4 * D, D, ops.EPI_BF16_GELU),
