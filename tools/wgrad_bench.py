@@ -3,8 +3,10 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import p4p_amd
 from p4p_amd import ops, _lib
+if os.environ.get('P4P_DEBUG_LIB'):          # A/B of two builds of the library in one gpurun call
+    _lib.LIB_PATH = os.path.abspath(os.environ['P4P_DEBUG_LIB'])
 lib = _lib.lib()
-M, D = 256 * 257, 768
+M, D = int(os.environ.get('GB_M', 256 * 257)), 768
 g = torch.Generator().manual_seed(0)
 shapes = {'qkv': (3 * D, D), 'proj': (D, D), 'fc1': (4 * D, D), 'fc2': (D, 4 * D)}
 for name, (n, k) in shapes.items():
