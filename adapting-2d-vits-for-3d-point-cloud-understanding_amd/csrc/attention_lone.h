@@ -87,6 +87,7 @@ __device__ __forceinline__ void lone_fwd_tile(const char* klds, const char* vlds
     l = lacc[0] + pl;
 }
 
+#define LONE_OSLAB (16 * 144)  // per-wave output slab: 16 rows x (128 B + 16): rows leave as whole 128-B segments
 #define LONE_NW 4          // waves per workgroup: 2 workgroups per CU = 2 waves per SIMD, 256 VGPRs each (64 n + 1 <= 257 scores
                            // per lane stay in registers); the independent MFMA batches of the two passes give the overlap
 // Diagnostic build only (tools/attn_stamps.py compiles attention.hip with -DP4P_LONE_STAMPS into its own library): s_memtime
@@ -105,7 +106,7 @@ __device__ __forceinline__ void lone_fwd_tile(const char* klds, const char* vlds
 
 template <int NT>
 __global__ __launch_bounds__(LONE_NW * 64, 2) void attn_fwd_lone_res_kernel(AttnParams p) {
-    __shared__ __attribute__((aligned(1024))) char lds[2 * NT * TILE_BYTES + NT * LONE_PART_STRIDE * 4];
+    __shared__ __attribute__((aligned(1024))) char lds[2 * NT * TILE_BYTES + NT * LONE_PART_STRIDE * 4 + LONE_NW * LONE_OSLAB];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, i = lane & 15, g = lane >> 4;
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
     const int T = p.T, D = p.D, TL = T - 1;                 // T = 64 NT + 1; TL = the last row
@@ -157,12 +158,27 @@ __global__ __launch_bounds__(LONE_NW * 64, 2) void attn_fwd_lone_res_kernel(Attn
         float l, m;
         lone_fwd_tile<NT>(klds, vlds, qf, frag_dot(qf, kl), vl, c, lane, o, l, m);
         const float inv = 1.0f / l;
-        __bf16* dst = p.out + ((size_t)b * T + q) * D + h * HD;
+        // the accumulator layout would store 16 rows x 32 B per instruction; through the wave's slab the tile leaves as
+        // 8 rows x 128 B per instruction (this head's whole 128-B segment of an output row)
+        char* oslab = lds + 2 * NT * TILE_BYTES + NT * LONE_PART_STRIDE * 4 + wave * LONE_OSLAB;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             bf16x4 w = {f2bf(o[d][0] * inv), f2bf(o[d][1] * inv), f2bf(o[d][2] * inv), f2bf(o[d][3] * inv)};
-            *reinterpret_cast<bf16x4*>(dst + d * 16 + 4 * g) = w;
+            *reinterpret_cast<bf16x4*>(oslab + i * 144 + d * 32 + g * 8) = w;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int r = h2 * 8 + (lane >> 3), cc = lane & 7;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(oslab + r * 144 + cc * 16);
+            const int qr = (wave + LONE_NW * sidx) * 16 + r;
+            *reinterpret_cast<u32x4*>(p.out + ((size_t)b * T + qr) * D + h * HD + cc * 8) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (g == 0 && p.lse2) p.lse2[((size_t)b * p.H + h) * T + q] = m + __builtin_amdgcn_logf(l);
         if (sidx == 0) LONE_STAMP(3);
     }
