@@ -84,8 +84,8 @@ __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 
             auto fetch = [&](int j) {
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
-                    nxt[h] = q1 ? *reinterpret_cast<const f32x4*>(q1 + (size_t)row_at(j, h) * p.N) : f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (q2) nxt[h] += *reinterpret_cast<const f32x4*>(q2 + (size_t)row_at(j, h) * p.N);
+                    nxt[h] = q1 ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q1 + (size_t)row_at(j, h) * p.N)) : f32x4{0.f, 0.f, 0.f, 0.f};   // read once
+                    if (q2) nxt[h] += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q2 + (size_t)row_at(j, h) * p.N));
                 }
             };
             fetch(0);
@@ -190,7 +190,7 @@ __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 
             for (int h2 = 0; h2 < 2; ++h2) {
                 int m = rowbase + j * 16 + h2 * 8 + (lane >> 3);
                 m = m < p.M ? m : p.M - 1;
-                hrows[h2] = *reinterpret_cast<const u32x4*>(hsrc_r + (size_t)m * p.N);
+                hrows[h2] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(hsrc_r + (size_t)m * p.N));   // read once (proj +3-7 %, dfc2 +1-3 % with the residual / derivative loads non-temporal)
             }
         } else {
 #pragma unroll
