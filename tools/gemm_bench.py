@@ -33,7 +33,7 @@ for name, (m, n, k, epi) in shapes.items():
             if rnd == 0:
                 o = out.float().clone()
                 if ref is None: ref = o
-                elif v < 20: assert torch.allclose(o, ref, rtol=2e-2, atol=2e-2), (name, v, float((o - ref).abs().max()))
+                elif v < 20 and not os.environ.get('GB_NOCHECK'): assert torch.allclose(o, ref, rtol=2e-2, atol=2e-2), (name, v, float((o - ref).abs().max()))
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             for _ in range(10): f()
