@@ -27,6 +27,7 @@ __device__ float g_zero_page[64];   // 256 B of zeros: LDS-DMA source for rows p
 #include "gemm_tn.h"
 #include "gemm_tn3.h"
 #include "gemm_tn4.h"
+#include "gemm_tn4p.h"
 #include "gemm_wgrad3.h"
 
 #define GEMM_THREADS 256
@@ -34,6 +35,8 @@ __device__ float g_zero_page[64];   // 256 B of zeros: LDS-DMA source for rows p
 // tile configuration: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x128 (8 waves), 3 = 256x256 (8 waves),
 // 4 = 256x128 / 4 waves / K-step 32 / 3-stage ring (gemm_tn3.h); 11-13 = 1-3 with pinned scheduling
 static int g_gemm_variant = 0;
+static int g_tn4_persistent = 1;            // A/B switch: 0 = one workgroup per tile (gemm_tn4.h) everywhere
+extern "C" int p4p_set_gemm_persistent(int v) { int o = g_tn4_persistent; g_tn4_persistent = v; return o; }
 extern "C" int p4p_set_gemm_variant(int v) { int o = g_gemm_variant; g_gemm_variant = v; return o; }
 
 // ---- split-K for the short, wide tail launches (few workgroups, long K loop: latency-bound at one K-step per ~0.5 us)
@@ -197,6 +200,13 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
         if (v == 10) {                                       // 256 x 256, staggered 4-phase schedule (gemm_tn4.h)
             if (p.N % 256 == 0 && (unsigned long long)p.M * p.K * 2 < (1ull << 32) && (unsigned long long)p.N * p.K * 2 < (1ull << 32)) {
                 int tiles = ceil_div(p.M, 256) * (p.N / 256);
+                // several tiles per CU and an even number (>= 4) of K-tiles: the persistent loop of gemm_tn4p.h hides the per-tile
+                // dispatch + pipeline-fill latency behind the previous tile's epilogue
+                if (g_tn4_persistent && tiles >= 512 && p.K % 128 == 0 && p.K >= 256 && p.K <= 2304) {
+                    hipLaunchKernelGGL((gemm_tn4p_kernel<EPI>), dim3(256), dim3(512), 0, st, p);
+                    P4P_LAUNCH_CHECK();
+                    return 0;
+                }
                 hipLaunchKernelGGL((gemm_tn4_kernel<EPI>), dim3(tiles), dim3(512), 0, st, p);
                 P4P_LAUNCH_CHECK();
                 return 0;

@@ -53,8 +53,8 @@ struct T3Frags {
 // The caller guarantees that no wave reads the operand ring any more (the slabs live at `lds`, 4.5 KiB per wave).
 // =================================================================================================
 template <int EPI, bool LDS_FREE = false>
-__device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 (&acc)[4][8], char* lds, int tm, int m0,
-                                                     int n0, int wm, int wn, int wave, int lane) {
+__device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 (&acc)[4][8], char* wslab, int tm, int m0,
+                                                     int n0, int wm, int wn, int wave, int lane) {      // wslab: this wave's 4.5 KiB
     const int li = lane & 15, g = lane >> 4;
     const int rowbase = m0 + wm * 128, colbase = n0 + wn * 64;
     f32x4 bias4[4];
@@ -75,7 +75,7 @@ __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 
             // rows through the wave's LDS slab: every global access (residual reads, output stores) is 4 whole 256-B row
             // segments per instruction instead of 16 rows x 64 B; the sums keep their association ((acc + bias) + resid)
             constexpr int FS = 272;                          // 256-B rows + 16
-            char* fslab = lds + wave * 4608;
+            char* fslab = wslab;
             const int rr = lane >> 4, cc = lane & 15;
             const float* q1 = p.resid ? p.resid + (size_t)colbase + cc * 4 : nullptr;
             const float* q2 = p.rowgrp ? p.rowgrp + (size_t)colbase + cc * 4 : nullptr;
@@ -150,7 +150,7 @@ __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 
     // ---- bf16 outputs
     constexpr int SLAB_STRIDE = 144;                       // 128-B rows + 16: conflict-free 8-B writes, 16-B aligned reads
     constexpr int SLAB_BYTES = 16 * SLAB_STRIDE;
-    char* slab = lds + wave * (2 * SLAB_BYTES);            // [out | pre] per wave
+    char* slab = wslab;                                    // [out | pre] per wave
     const int wr_off = li * SLAB_STRIDE + g * 8;           // + i*32
     // the wave's own ds_writes and ds_reads execute in order; the fences only stop hipcc from moving them
     auto wave_lds_sync = [&]() {
@@ -444,5 +444,5 @@ __global__ __launch_bounds__(BN_ * 2, 2) void gemm_tn3_kernel(GemmParams p) {
 #undef T3_ITER
 
     __builtin_amdgcn_sched_barrier(0);
-    tile_epilogue_128x64<EPI>(p, acc, lds, tm, m0, n0, wm, wn, wave, lane);
+    tile_epilogue_128x64<EPI>(p, acc, lds + wave * 4608, tm, m0, n0, wm, wn, wave, lane);
 }

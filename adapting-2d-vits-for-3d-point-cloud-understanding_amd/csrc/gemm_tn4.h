@@ -191,5 +191,5 @@ __global__ __launch_bounds__(512) void gemm_tn4_kernel(GemmParams p) {
 #undef T4_MFMA_SECTION
     if (wm == 0) __builtin_amdgcn_s_barrier();             // group 0 catches up: every wave has executed the same count
     __builtin_amdgcn_sched_barrier(0);
-    tile_epilogue_128x64<EPI, true>(p, acc, lds, tm, m0, n0, wm, wn, wave, lane);
+    tile_epilogue_128x64<EPI, true>(p, acc, lds + wave * 4608, tm, m0, n0, wm, wn, wave, lane);
 }

@@ -199,6 +199,39 @@ def test_gemm_tn_big_tile_kernels_exact_on_integer_data(M, variant):
     assert torch.equal(dgelu, ref_dgelu)
 
 
+@pytest.mark.parametrize('M,N,K', [(300 * 256, 768, 256), (300 * 256 - 100, 768, 768), (513 * 128, 1024, 384), (257 * 256, 2304, 768),
+                                   (700 * 256 + 17, 256, 2304), (1100 * 256, 256, 128)])
+def test_gemm_tn_persistent_tile_loop_is_exact_and_equals_the_per_tile_kernel(M, N, K):
+    """gemm_tn4p.h (several tiles per workgroup, the next tile's first K-tiles staged across the seam, counted waits over the
+    epilogue's own stores): exact on integer operands, bit-identical to the one-workgroup-per-tile kernel for every epilogue,
+    with a ragged last row panel (no seam there), with 2 .. 4+ tiles per workgroup, and K that is not eligible (128: plain path)."""
+    from p4p_amd import _lib
+    lib = _lib.lib()
+    a = _int_bf16((M, K), -2, 2, 21).to(DEV)
+    w = (_int_bf16((N, K), -1, 1, 22) * (torch.rand(N, K, generator=torch.Generator().manual_seed(5)) < (0.25 if K > 512 else 1.0))).to(torch.bfloat16).to(DEV)
+    want = a.float() @ w.float().t()
+    bias = torch.arange(N, device=DEV, dtype=torch.float32) % 5 - 2
+    resid = (torch.arange(M * N, device=DEV) % 11 - 5).float().view(M, N)
+    pre = (torch.arange(M * N, device=DEV) % 7 - 3).to(torch.bfloat16).view(M, N)
+    outs = {}
+    for mode in (0, 1):
+        old = lib.p4p_set_gemm_persistent(mode)
+        try:
+            outs[mode] = (ops.gemm_tn(a, w, ops.EPI_BF16, bias=bias),
+                          ops.gemm_tn(a, w, ops.EPI_F32_RESID, bias=bias, resid=resid),
+                          ops.gemm_tn(a, w, ops.EPI_BF16_GELU, bias=bias, want_pre=True),
+                          ops.gemm_tn(a, w, ops.EPI_BF16_DGELU, pre=pre, want_colsum=True))
+        finally:
+            lib.p4p_set_gemm_persistent(old)
+    assert torch.equal(outs[1][0], (want + bias).to(torch.bfloat16))
+    assert torch.equal(outs[1][1], (want + bias) + resid)
+    for x, y in zip(outs[0], outs[1]):
+        if isinstance(x, tuple):
+            assert all(torch.equal(u, v) for u, v in zip(x, y))
+        else:
+            assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize('K', [2304, 3072])
 def test_gemm_tn_split_k_tail_exact_on_integer_data(K):
     """M = 257 panels of 256 rows, N = 768: three full rounds of 256x256 tiles plus one panel, which is peeled off and --
