@@ -232,6 +232,32 @@ def test_gemm_tn_persistent_tile_loop_is_exact_and_equals_the_per_tile_kernel(M,
             assert torch.equal(x, y)
 
 
+def test_gemm_tn_persistent_tile_loop_token_stream_rows():
+    """The tokenizer -> token-stream projection at the benchmark's size (B = 256 clouds of S = 256 tokens, 256 -> 768): the fp32
+    epilogue writes row m of the compact [B*S] rows to row m + m/S + 1 of the [B*(S+1)] stream (one cls row in front of every
+    sequence, pix4point.py:248-252 without the torch.cat).  768 tiles, three per workgroup: the persistent kernel; exact on
+    integer data, cls rows untouched, identical to the per-tile kernel."""
+    from p4p_amd import _lib
+    lib = _lib.lib()
+    B, S, N, K = 256, 256, 768, 256
+    a = _int_bf16((B * S, K), -2, 2, 31).to(DEV)
+    w = _int_bf16((N, K), -1, 1, 32).to(DEV)
+    bias = torch.arange(N, device=DEV, dtype=torch.float32) % 7 - 3
+    want = (a.float() @ w.float().t() + bias).view(B, S, N)
+    outs = []
+    for mode in (0, 1):
+        old = lib.p4p_set_gemm_persistent(mode)
+        try:
+            out = torch.full((B * (S + 1), N), -777.0, device=DEV)
+            ops.gemm_tn(a, w, ops.EPI_F32_RESID, bias=bias, group=S, out=out)
+        finally:
+            lib.p4p_set_gemm_persistent(old)
+        outs.append(out.view(B, S + 1, N))
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[1][:, 1:], want)
+    assert bool((outs[1][:, 0] == -777.0).all())
+
+
 @pytest.mark.parametrize('K', [2304, 3072])
 def test_gemm_tn_split_k_tail_exact_on_integer_data(K):
     """M = 257 panels of 256 rows, N = 768: three full rounds of 256x256 tiles plus one panel, which is peeled off and --
