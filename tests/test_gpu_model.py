@@ -235,6 +235,26 @@ def _no_dropout(*models):
                 m.p = 0.0
 
 
+@pytest.mark.parametrize('vit,D,B,N', [('vit_base_patch16_384', 768, 256, 1024), ('vit_base_patch16_384', 768, 128, 2048)])
+def test_full_size_eval_logits_do_not_depend_on_the_batch_they_ride_in(vit, D, B, N):
+    """A size-independent property for the full-size configurations, which the oracle cannot run in seconds: in eval mode a
+    cloud's logits are a function of that cloud alone, so the first clouds of a B-cloud batch (persistent GEMM tile loops, the
+    peeled row panels, chip-filling attention grids) must give the logits of the same clouds run as a batch of 4 (per-tile
+    kernels, small grids) up to the bf16 noise of the differently ordered sums (the bound of the fp32-oracle comparison);
+    measured 0 to a few 1e-3."""
+    torch.manual_seed(0)
+    model = p4p_amd.Pix4Point(num_classes=40, embed_dim=D, pretrained_model=vit, pretrained=False).to(DEV).eval()
+    pts = O.synthetic_clouds(B, N, seed=9).to(DEV)
+    start = torch.randint(0, N, (B,), generator=torch.Generator().manual_seed(10)).to(DEV)
+    with torch.no_grad():
+        big = model(pts, start)
+        for a in (0, B // 2 - 1, B - 4):
+            small = model(pts[a:a + 4].contiguous(), start[a:a + 4].contiguous())
+            err = float((big[a:a + 4] - small).abs().max())
+            assert err <= LOGIT_TOL * max(1.0, float(small.abs().max())), (a, err)
+    assert bool(torch.isfinite(big).all())
+
+
 def test_train_mode_gradients_vs_oracle():
     """Train-mode forward + backward of tokenizer + encoder against the fp32 oracle, with a smooth,
     well-conditioned loss on the global feature (pix4point.py:262-269).  The classification head is stock
