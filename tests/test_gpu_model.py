@@ -255,6 +255,38 @@ def test_full_size_eval_logits_do_not_depend_on_the_batch_they_ride_in(vit, D, B
     assert bool(torch.isfinite(big).all())
 
 
+@pytest.mark.parametrize('vit,D,B,N', [('vit_base_patch16_384', 768, 256, 1024), ('vit_base_patch16_384', 768, 128, 2048)])
+def test_full_size_backward_is_additive_over_the_batch(vit, D, B, N):
+    """The backward pass at full size, checked through a property instead of the oracle: with every batch-coupling layer in eval
+    mode (tokenizer frozen -- its backward exists for train-mode BatchNorm only --, head BatchNorm on running statistics, dropout
+    off) the summed cross-entropy is a sum over clouds, so the gradient of the whole batch equals the sum of the gradients of
+    its two halves.  The whole batch runs the chip-filling paths (weight-gradient GEMMs split over M with slab reduction,
+    persistent dgrad GEMMs, full attention grids), the halves different splits / tilings.  Measured 1.6e-3 relative (bf16 operand
+    rounding of differently shaped reductions); a wrong split, a lost slab or a mis-staged seam is O(1)."""
+    torch.manual_seed(0)
+    model = p4p_amd.Pix4Point(num_classes=40, embed_dim=D, pretrained_model=vit, pretrained=False).to(DEV).eval()
+    for prm in model.model.patch_embed.parameters():
+        prm.requires_grad_(False)
+    pts = O.synthetic_clouds(B, N, seed=9).to(DEV)
+    start = torch.randint(0, N, (B,), generator=torch.Generator().manual_seed(10)).to(DEV)
+    labels = torch.randint(0, 40, (B,), generator=torch.Generator().manual_seed(11)).to(DEV)
+
+    def grads(sl):
+        model.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.cross_entropy(model(pts[sl].contiguous(), start[sl].contiguous()), labels[sl], reduction='sum')
+        loss.backward()
+        return float(loss.detach()), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    lf, gf = grads(slice(0, B))
+    l1, g1 = grads(slice(0, B // 2))
+    l2, g2 = grads(slice(B // 2, B))
+    assert abs(lf - (l1 + l2)) <= 1e-4 * abs(lf)
+    assert len(gf) > 150 and set(gf) == set(g1) == set(g2)
+    for n in gf:
+        rel = float((gf[n] - (g1[n] + g2[n])).norm() / gf[n].norm().clamp_min(1e-12))
+        assert rel < 6e-3, (n, rel)
+
+
 def test_train_mode_gradients_vs_oracle():
     """Train-mode forward + backward of tokenizer + encoder against the fp32 oracle, with a smooth,
     well-conditioned loss on the global feature (pix4point.py:262-269).  The classification head is stock
