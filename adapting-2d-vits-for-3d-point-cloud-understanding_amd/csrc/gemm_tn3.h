@@ -80,12 +80,14 @@ __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 
             const float* q1 = p.resid ? p.resid + (size_t)colbase + cc * 4 : nullptr;
             const float* q2 = p.rowgrp ? p.rowgrp + (size_t)colbase + cc * 4 : nullptr;
             auto row_at = [&](int j, int h) { int m = rowbase + j * 16 + h * 4 + rr; return m < p.M ? m : p.M - 1; };
-            f32x4 nxt[4];
+            // the two residual streams stay in separate registers until the slab that uses them: adding them at fetch time made
+            // hipcc wait for both loads on the spot (vmcnt(0) four times per slab, one slab ahead of need)
+            f32x4 nxt[4], nxt2[4];
             auto fetch = [&](int j) {
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     nxt[h] = q1 ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q1 + (size_t)row_at(j, h) * p.N)) : f32x4{0.f, 0.f, 0.f, 0.f};   // read once
-                    if (q2) nxt[h] += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q2 + (size_t)row_at(j, h) * p.N));
+                    nxt2[h] = q2 ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q2 + (size_t)row_at(j, h) * p.N)) : f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             };
             fetch(0);
@@ -93,7 +95,7 @@ __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 
             for (int j = 0; j < 8; ++j) {
                 f32x4 cur[4];
 #pragma unroll
-                for (int h = 0; h < 4; ++h) cur[h] = nxt[h];
+                for (int h = 0; h < 4; ++h) cur[h] = q2 ? nxt[h] + nxt2[h] : nxt[h];
                 if (j + 1 < 8 && q1) fetch(j + 1);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)

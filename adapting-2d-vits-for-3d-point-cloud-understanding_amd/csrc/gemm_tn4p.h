@@ -22,12 +22,15 @@
 //   catch-up barrier : group 0 waits for group 1 as in gemm_tn4.h; after it nobody reads the ring.
 //   epilogue         : the 7 staged half-tiles sit in slots c .. c+6 (c = slot of the next tile's B0); the per-wave slabs go to the
 //                      three free slots c+7 .. c+9 (three 4.5-KiB slabs per 16-KiB slot).
-//   wait before the next tile: vmcnt counts the epilogue's own loads / stores too, and they were issued AFTER the seam's DMAs.
-//                      vmcnt retires in issue order, so `s_waitcnt vmcnt(8)` -- at most 8 operations outstanding -- implies that
-//                      everything older than the newest 8 is done; a full tile's epilogue issues at least 16 vector-memory
-//                      operations per wave (2 stores per 16-row slab), so the newest 8 are all epilogue stores and every DMA has
-//                      landed.  Only a LOWER bound on the epilogue's operation count is assumed (a seam exists only behind a full
-//                      tile).
+//   wait before the next tile: `s_waitcnt vmcnt(6)`, the wait of gemm_tn4.h's prologue, although vmcnt now also counts the
+//                      epilogue's own loads / stores, all issued AFTER the seam's 14 DMA instructions.  If vmcnt retires strictly
+//                      in issue order (what hipcc assumes on this target, and the guide's "vmcnt counts stores too"), at most 6
+//                      outstanding means that everything older than the newest 6 is done: a full tile's epilogue issues >= 16
+//                      operations per wave, so every DMA has landed.  If only loads are ordered among loads and stores among
+//                      stores, the worst case is that all stores are done and the 6 outstanding are the newest loads -- the DMAs
+//                      of half-tiles 4..6 at most, exactly what the prologue of gemm_tn4.h leaves in flight; the counted waits of
+//                      the first K-tiles then retire them as there.  Either way half-tiles 0..3 are in LDS, and nothing is assumed
+//                      about the epilogue's operation count beyond "a seam exists only behind a full tile".
 //   first K-tiles of the next tile: their counted waits see a few old stores in front of the DMAs: stricter, never weaker.
 //   exit             : vmcnt(0): no DMA may outlive the workgroup's LDS allocation.
 #pragma once
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(512) void gemm_tn4p_kernel(GemmParams p) {
         }
         __builtin_amdgcn_sched_barrier(0);
         if (seam) {
-            WAIT_VM(8);                                    // file header: a lower bound on the epilogue's vector-memory operations
+            WAIT_VM(6);                                    // file header: the first four half-tiles have landed under either ordering model
         } else {
             WAIT_VM(0);                                    // the placeholder half-tiles have landed: their slots can be staged again
             st_slot = c_slot;
