@@ -54,14 +54,18 @@ struct T3Frags {
 // =================================================================================================
 template <int EPI, bool LDS_FREE = false>
 __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 (&acc)[4][8], char* wslab, int tm, int m0,
-                                                     int n0, int wm, int wn, int wave, int lane) {      // wslab: this wave's 4.5 KiB
+                                                     int n0, int wm, int wn, int wave, int lane,
+                                                     const f32x4* bias_pre = nullptr) {      // wslab: this wave's 4.5 KiB
     const int li = lane & 15, g = lane >> 4;
     const int rowbase = m0 + wm * 128, colbase = n0 + wn * 64;
+    // bias_pre: the caller loaded this wave's 4 bias vectors ahead of the K loop (gemm_tn4p.h: loaded here they are four
+    // load + vmcnt(0) pairs at the head of the epilogue, and under the persistent loop each vmcnt(0) also drains the seam's DMAs)
     f32x4 bias4[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         bias4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bias4[i] = *reinterpret_cast<const f32x4*>(p.bias + colbase + i * 16 + g * 4);
+        if (bias_pre) bias4[i] = bias_pre[i];
+        else if (p.bias) bias4[i] = *reinterpret_cast<const f32x4*>(p.bias + colbase + i * 16 + g * 4);
     }
 
     if (EPI == EPI_F32_RESID) {

@@ -153,6 +153,10 @@ __global__ __launch_bounds__(512) void gemm_tn4p_kernel(GemmParams p) {
         };
 #define T4P_STAGE(s, us) issue(s, (us) < nk ? (long long)(us) * 128 : (long long)((us) - nk) * 128 + ((s) < 2 ? dW : dA))
 
+        f32x4 bias4[4];                                    // ahead of the K loop: see tile_epilogue_128x64
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            bias4[i] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 64 + i * 16 + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(512) void gemm_tn4p_kernel(GemmParams p) {
         __builtin_amdgcn_sched_barrier(0);
         {
             const int sl = slot_of(c_slot, 7 + wave / 3);      // the three slots no staged half-tile occupies
-            tile_epilogue_128x64<EPI, true>(p, acc, lds + sl * T4_HT + (wave % 3) * 4608, tm, m0, n0, wm, wn, wave, lane);
+            tile_epilogue_128x64<EPI, true>(p, acc, lds + sl * T4_HT + (wave % 3) * 4608, tm, m0, n0, wm, wn, wave, lane, bias4);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (seam) {
