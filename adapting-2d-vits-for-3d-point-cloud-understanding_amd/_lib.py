@@ -25,14 +25,28 @@ def declared_symbols():
     return sorted(set(re.findall(r'\b(p4p_[a-z0-9_]+)\s*\(', text)))
 
 
+def header_abi_version():
+    """P4P_ABI_VERSION of include/p4p_hip.h: the ABI this Python package was written against."""
+    m = re.search(r'#define\s+P4P_ABI_VERSION\s+(\d+)', open(HEADER_PATH).read())
+    if m is None:
+        raise P4PError(f'{HEADER_PATH}: P4P_ABI_VERSION not found')
+    return int(m.group(1))
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise P4PError(f'{LIB_PATH} not found: the HIP library has not been built '
                            '(run __graft_entry__.build()); there is no fallback path')
-        _lib = ctypes.CDLL(LIB_PATH)
-        _lib.p4p_last_error.restype = ctypes.c_char_p
+        cand = ctypes.CDLL(LIB_PATH)
+        cand.p4p_last_error.restype = ctypes.c_char_p
+        cand.p4p_abi_version.restype = ctypes.c_int
+        have, want = int(cand.p4p_abi_version()), header_abi_version()
+        if have != want:
+            raise P4PError(f'{LIB_PATH} implements ABI version {have}, include/p4p_hip.h declares {want}: the library is '
+                           'stale (argument lists differ) -- rebuild it with __graft_entry__.build()')
+        _lib = cand
     return _lib
 
 

@@ -1,5 +1,6 @@
 // Error channel and version of the C ABI (include/p4p_hip.h).
 #include "common.h"
+#include "../../include/p4p_hip.h"
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -12,7 +13,7 @@ void p4p_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* p4p_last_error(void) { return g_err; }
-extern "C" int p4p_abi_version(void) { return 1; }
+extern "C" int p4p_abi_version(void) { return P4P_ABI_VERSION; }
 
 // ---- optional launch profiler: HIP events around exactly one kernel launch (bench.py's roofline) --------
 // kind 1 = weight-gradient GEMM main kernel, kind 2 = gemm_tn main kernel, kind 3 = attention forward, kind 4 = attention

@@ -11,7 +11,9 @@ is the gradient all-reduce.  Design:
   vectors are copied.  ``block_done`` then launches that bucket's all-reduce asynchronously on RCCL's stream,
   overlapping with the backward of the remaining blocks.  Nothing is added into the buffer, so only the tail bucket
   (whose gradients autograd accumulates) is zeroed per step.
-* ``finish`` (after ``loss.backward()``) reduces the tail bucket and waits for all handles.  The buffer then holds SUMS;
+* ``finish`` (after ``loss.backward()``) zeroes every block region the step's backward did not write (a loss that does
+  not reach the encoder), reduces the tail bucket and waits for all handles.  The buffer -- and therefore every
+  ``p.grad`` a logger or a custom clipper reads afterwards -- then holds SUMS over the ranks, not means;
   ``grad_scale`` = 1/world goes to ``FusedAdamW.step(grad_scale=...)``, which folds it into the clip coefficient (no
   pass over the 345-MB buffer); ``finish(average=True)`` scales in place for a stock optimizer.
   BatchNorm statistics stay per rank (what a per-rank reference run would compute).
@@ -37,6 +39,7 @@ class GradReducer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.grad_scale = 1.0 / self.world
         self.buckets = []
+        self._regions = {}                 # id(first parameter of a block) -> [bucket, start, end, written this step]
         params = [p for b in bucket_params for p in b]
         if not params:
             raise ValueError('GradReducer: no parameters')
@@ -55,6 +58,25 @@ class GradReducer:
         self._have = [0] * len(bucket_params)
         self._handles = []
         self._launched = set()
+        self._trainable = [(p, p.requires_grad) for p in params]
+        self._stale_zeroed = 0             # regions finish() had to zero (a block whose backward did not write): diagnostic
+
+    def register_block(self, params: Iterable[torch.nn.Parameter]):
+        """Declare one block (a run of consecutive parameters of one bucket that the backward writes as a unit): finish()
+        zeroes the region of every registered block whose block_done did not arrive in the step."""
+        params = list(params)
+        i = self._bucket_of[id(params[0])]
+        s = params[0].grad.data_ptr() - self.flat.data_ptr()
+        e = params[-1].grad.data_ptr() - self.flat.data_ptr() + params[-1].numel() * 4
+        self._regions[id(params[0])] = [i, s // 4, e // 4, False]
+
+    def check_trainable(self):
+        """The bucket layout is fixed at construction: a requires_grad flag flipped afterwards (staged unfreezing) would leave
+        a block without its per-step write (stale sums) or a gradient outside the buffer.  Rebuild the reducer instead."""
+        for p, was in self._trainable:
+            if p.requires_grad != was:
+                raise RuntimeError('GradReducer: requires_grad of a bucketed parameter changed after build_reducer(); '
+                                   'build a new reducer for the new set of trainable parameters')
 
     # -- called from inside backward ---------------------------------------------------------
     def grad_views(self, params: Iterable[torch.nn.Parameter]):
@@ -67,7 +89,11 @@ class GradReducer:
 
     def block_done(self, params: Iterable[torch.nn.Parameter]):
         """One block's gradients are in its views: count it, and launch the bucket's all-reduce when it is complete."""
-        i = self._bucket_of[id(next(iter(params)))]
+        first = next(iter(params))
+        i = self._bucket_of[id(first)]
+        reg = self._regions.get(id(first))
+        if reg is not None:
+            reg[3] = True
         self._have[i] += 1
         if self._have[i] >= self._need[i]:
             self._launch(i)
@@ -99,6 +125,16 @@ class GradReducer:
     def finish(self, average=True):
         """Reduce what is left, wait for everything.  average=True divides by the world size in place (stock optimizers);
         average=False leaves SUMS and the caller passes ``grad_scale`` to FusedAdamW.step."""
+        self.check_trainable()
+        for reg in self._regions.values():
+            # a block bucket is only correct if its backward OVERWROTE its views in this step (zero_grad() leaves them
+            # alone); a block the loss did not reach keeps last step's sums, so it is zeroed here, before its all-reduce
+            if not reg[3]:
+                if reg[0] in self._launched:
+                    raise RuntimeError('GradReducer: a bucket was reduced before all of its blocks were written')
+                self.flat[reg[1]:reg[2]].zero_()
+                self._stale_zeroed += 1
+            reg[3] = False
         for i in range(len(self.buckets)):
             self._launch(i)
         for h in self._handles:
@@ -110,7 +146,8 @@ class GradReducer:
             self.flat.mul_(self.grad_scale)
 
     def zero_grad(self):
-        """Only the tail bucket accumulates (autograd adds into its views); the block buckets are overwritten."""
+        """Only the tail bucket accumulates (autograd adds into its views); the block buckets are overwritten by the
+        encoder's backward (finish() zeroes any registered block that was NOT written in a step)."""
         s, e = self.buckets[-1]
         self.flat[s:e].zero_()
 
@@ -140,6 +177,10 @@ def build_reducer(model, process_group=None, bucket_mb=None) -> GradReducer:
     buckets.append(tail)
     counts.append(0)
     red = GradReducer(buckets, process_group, blocks_per_bucket=counts)
+    for blk in blocks:
+        bp = [p for p in block_params(blk) if p.requires_grad]
+        if bp and len(bp) == 12:
+            red.register_block(bp)
     pv.grad_sink = red
     return red
 

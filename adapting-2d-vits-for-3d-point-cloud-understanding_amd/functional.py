@@ -55,11 +55,16 @@ def refresh_weight_operands(weights, want_t):
     recs = []
     for w, ent in stale:
         R, C = w.shape
-        wb = ent[1] if ent is not None else torch.empty(R, C, dtype=torch.bfloat16, device=w.device)
-        wt = ent[2] if (ent is not None and ent[2] is not None) else (
+        # the old buffers are reused only if they still fit this weight (after model.to(another GPU) or a replaced
+        # .data they sit on the old device / have the old shape: writing through them would corrupt other memory)
+        def fits(t, shape):
+            return t is not None and t.device == w.device and tuple(t.shape) == shape and t.dtype == torch.bfloat16
+        wb = ent[1] if (ent is not None and fits(ent[1], (R, C))) else torch.empty(R, C, dtype=torch.bfloat16, device=w.device)
+        wt = ent[2] if (ent is not None and fits(ent[2], (C, R))) else (
             torch.empty(C, R, dtype=torch.bfloat16, device=w.device) if want_t else None)
         recs.append((w, wb, wt))
-    key = tuple((w.data_ptr(), wb.data_ptr(), 0 if wt is None else wt.data_ptr()) for w, wb, wt in recs)
+    key = tuple((w.data_ptr(), wb.data_ptr(), 0 if wt is None else wt.data_ptr(), w.shape[0], w.shape[1], w.device.index)
+                for w, wb, wt in recs)
     tab = _multi_tables.get(key)
     if tab is None:
         import struct

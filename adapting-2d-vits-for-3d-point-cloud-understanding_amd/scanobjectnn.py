@@ -8,7 +8,7 @@ Differences, stated:
   float32 and ``label`` (M,)) otherwise -- ``numpy.savez(path, data=f['data'][:], label=f['label'][:])`` converts a file;
 * dataset-level FPS (``sampling_method='fps'``, :92-97: ``fps(points.cuda(), num_points)`` over the WHOLE array in one
   Python-loop call) runs through the HIP kernel (``p4p_fps_f32``, bit-identical algorithm: tests/test_gpu_apf.py) in chunks of
-  clouds; the reference draws the start indices unseeded (sampler.py:20), here they come from ``fps_seed`` (None = unseeded);
+  clouds; the reference draws the start indices unseeded (sampler.py:20), here they come from ``fps_seed`` (None = unseeded; in a multi-rank run one seed drawn by rank 0 is shared, so all ranks subsample alike);
 * the per-sample numpy augmentations of ``__getitem__`` (:186-212) and the dict transforms of the APF trainer are applied to
   the DEVICE BATCH by the trainers (p4p_amd.augment: one kernel launch per batch, draw-for-draw parity with the reference's
   functions in tests/test_gpu_augment.py), so ``__getitem__`` returns the sampled (and, if asked, normalised) cloud;
@@ -85,6 +85,14 @@ class ScanObjectNN(Dataset):
         from . import ops
         M, P, C = self.data.shape
         n = min(self.num_points, P)
+        if seed is None:
+            # the reference is one process and draws unseeded; with several ranks every rank builds this dataset, and
+            # per-rank draws would evaluate the test split on DIFFERENT point subsets: all ranks take rank 0's draw
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                box = [int(torch.randint(0, 2 ** 31 - 1, (1,))) if dist.get_rank() == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                seed = box[0]
         gen = torch.Generator().manual_seed(seed) if seed is not None else None
         out = np.empty((M, n, C), dtype=np.float32)
         for a in range(0, M, chunk):

@@ -389,7 +389,8 @@ def allreduce_exposed_ms(stepper, batch, steps=3):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--gpus', type=int, default=None,
+                    help='ranks = GPUs of this node (default: WORLD_SIZE when a launcher set it, else 1)')
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', choices=('pix4point', 'apf'), default='pix4point',
@@ -417,6 +418,8 @@ def main():
     args.dim = args.dim or vd
 
     world_env = os.environ.get('WORLD_SIZE')
+    if args.gpus is None:          # `torchrun --nproc-per-node N bench.py` without --gpus: the launcher's world is the answer
+        args.gpus = int(world_env or '1')
     if world_env is None and args.gpus > 1:
         sys.exit(spawn_ranks(args))
     world = int(world_env or '1')

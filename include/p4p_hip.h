@@ -18,6 +18,10 @@
 extern "C" {
 #endif
 
+/* Bumped on every incompatible change of a signature below (2: p4p_clip_coef gained grad_scale, p4p_apf_group gained C;
+ * 3: this round).  libp4p_hip.so is built separately from the Python package: the binding compares p4p_abi_version() with
+ * this constant when it loads the library and refuses a stale build. */
+#define P4P_ABI_VERSION 3
 int p4p_abi_version(void);
 const char* p4p_last_error(void);
 

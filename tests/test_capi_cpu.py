@@ -21,7 +21,15 @@ def test_every_declared_symbol_is_exported():
     assert len(names) >= 15
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/p4p_hip.h but not exported'
-    assert lib.p4p_abi_version() >= 1
+    assert lib.p4p_abi_version() == _lib.header_abi_version() >= 3
+
+
+def test_a_stale_library_is_refused(monkeypatch):
+    """the .so is built apart from the package; a build with another argument list must not be bound."""
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'header_abi_version', lambda: 999)
+    with pytest.raises(_lib.P4PError, match='stale'):
+        _lib.lib()
 
 
 def test_argument_checks_fail_loudly_without_launching():

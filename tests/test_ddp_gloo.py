@@ -111,3 +111,30 @@ def test_grad_reducer_single_process_is_identity():
     assert torch.equal(lin.weight.grad, g)
     red.zero_grad()
     assert float(lin.weight.grad.abs().max()) == 0.0
+
+
+def test_block_not_written_in_a_step_is_zeroed_not_reapplied():
+    """zero_grad() leaves the block buckets alone (their backward overwrites them), so a block whose backward
+    did not run in a step must not keep last step's sums: finish() zeroes every registered block without a block_done."""
+    blocks = [torch.nn.Linear(4, 4) for _ in range(2)]
+    tail = torch.nn.Linear(4, 2)
+    red = GradReducer([list(blocks[1].parameters()) + list(blocks[0].parameters()), list(tail.parameters())],
+                      blocks_per_bucket=[2, 0])
+    for b in blocks:
+        red.register_block(list(b.parameters()))
+    ones = [torch.ones_like(p) for p in blocks[0].parameters()]
+    for l in (1, 0):
+        red.block_ready(l, list(blocks[l].parameters()), ones)
+    red.finish(average=False)
+    assert all(float(p.grad.min()) == 1.0 for b in blocks for p in b.parameters())
+    # next step: the loss reaches block 1 only
+    red.zero_grad()
+    red.block_ready(1, list(blocks[1].parameters()), [2 * o for o in ones])
+    red.finish(average=False)
+    assert all(float(p.grad.min()) == 2.0 for p in blocks[1].parameters())
+    assert all(float(p.grad.abs().max()) == 0.0 for p in blocks[0].parameters()), 'stale sums survived'
+    assert red._stale_zeroed == 1
+    # a requires_grad flag flipped after construction is refused (the layout is fixed)
+    blocks[0].weight.requires_grad_(False)
+    with pytest.raises(RuntimeError, match='requires_grad'):
+        red.finish()
