@@ -14,7 +14,12 @@ the reference lines it follows (paths relative to the reference checkout):
   nor installed: **parity unpinned** for the block arithmetic.  It is restated from the in-repo
   textual statement ``src/models/apf_utils.py:142-158`` (attention) and ``:277-293`` (block
   wiring, minus the adapter) with timm's public defaults (LayerNorm eps 1e-6, exact-erf GELU,
-  qkv bias, MLP ratio 4).
+  qkv bias, MLP ratio 4).  Two partial pins narrow that gap: ``Attention`` reproduces the reference's own
+  ``AttentionLayer`` fixture bit for bit (tests/test_apf_oracle_golden.py), and ``Block`` (forward and
+  gradients, one block and a stack) agrees to fp32 rounding with Hugging Face ``transformers``' ``ViTLayer``
+  -- an independent implementation of the same published model family, installed in this image, under the
+  weight correspondence of its timm-checkpoint converter (tests/test_oracle_vs_hf_vit.py).  timm itself
+  stays unchecked.
 
 Policy differences that are deliberate and documented in DESIGN.md:
 
