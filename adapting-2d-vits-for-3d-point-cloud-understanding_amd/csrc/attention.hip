@@ -1183,9 +1183,10 @@ __global__ __launch_bounds__(RES_DKDV_NW * 64, 2) void attn_bwd_dkdv_res_kernel(
 }
 
 #include "attention_lone.h"
+#include "attention_fused.h"
 
 // experiment switch for tools/attn_ab.py (in-process A/B, default 0 = automatic): bit 0 = no resident forward / dQ,
-// bit 1 = no resident dK/dV, bit 2 = no two-pass (64 n + 1) forward.  Nothing in the product path sets it.
+// bit 1 = no resident dK/dV, bit 2 = no two-pass (64 n + 1) forward, bit 3 = no fused backward.  Nothing in the product path sets it.
 static int g_attn_variant = 0;
 extern "C" int p4p_set_attention_variant(int v) { int o = g_attn_variant; g_attn_variant = v; return o; }
 
@@ -1235,6 +1236,9 @@ extern "C" int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B,
 static bool attn_resident(int T) {
     return T <= RES_ROWS - 31 && T >= 64 && !(g_attn_variant & 1);
 }
+static bool attn_fused(int T) {           // attention_fused.h; needs the resident kernels' colsum layout (RES_COLSUM_ROWS rows per sequence)
+    return !(g_attn_variant & 8) && attn_resident(T) && !(g_attn_variant & 2) && (T == 65 || T == 129 || T == 257);
+}
 static bool attn_resident_dkdv(int T) {
     return !(g_attn_variant & 2) && attn_resident(T);       // 4 waves x 220 VGPRs: -0.4 ms/step
 }
@@ -1255,6 +1259,19 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
         ProfScope(double fl, hipStream_t s_) : s(s_), on(p4p_prof_begin(4, fl, s_)) {}
         ~ProfScope() { if (on) p4p_prof_end(s); }
     } prof_scope(10.0 * B * H * (double)T * T * HD, st);
+    AttnParams p = {};
+    p.qkv = (const __bf16*)qkv; p.o = (const __bf16*)o; p.dout = (const __bf16*)dout; p.out = (__bf16*)dqkv;
+    p.lse2 = (float*)lse2; p.delta = delta; p.colsum = colsum_partial; p.B = B; p.T = T; p.H = H; p.D = D; p.scale = scale;
+    if (attn_fused(T)) {                                 // T = 32 NT + 1 <= 257: one kernel, attention_fused.h
+        const dim3 grid(B * H);
+        switch ((T - 1) / 32) {
+            case 2: hipLaunchKernelGGL(attn_bwd_fused_kernel<2>, grid, dim3(2 * 64), 0, st, p); break;
+            case 4: hipLaunchKernelGGL(attn_bwd_fused_kernel<4>, grid, dim3(4 * 64), 0, st, p); break;
+            default: hipLaunchKernelGGL(attn_bwd_fused_kernel<8>, grid, dim3(8 * 64), 0, st, p); break;
+        }
+        P4P_LAUNCH_CHECK();
+        return 0;
+    }
     const bool res_dkdv = attn_resident_dkdv(T);
     const bool res = attn_resident(T) && (res_dkdv || !colsum_partial);
     const bool dq_q = !res && T > 128;                   // two query tiles per wave
@@ -1263,9 +1280,6 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
                            (const __bf16*)dout, delta, B, T, H, D);
         P4P_LAUNCH_CHECK();
     }
-    AttnParams p = {};
-    p.qkv = (const __bf16*)qkv; p.o = (const __bf16*)o; p.dout = (const __bf16*)dout; p.out = (__bf16*)dqkv;
-    p.lse2 = (float*)lse2; p.delta = delta; p.colsum = colsum_partial; p.B = B; p.T = T; p.H = H; p.D = D; p.scale = scale;
     dim3 grid = attn_grid(B, T, H);
     if (res) hipLaunchKernelGGL(attn_bwd_dq_res_kernel, dim3(B * H), dim3(RES_NW * 64), 0, st, p);
     else if (dq_q)

@@ -1,0 +1,426 @@
+// Fused attention backward for the model's own short sequences, T = 32 NT + 1 <= 257 (N = 1024 points: 256 point tokens + cls,
+// src/models/pix4point.py:248-252): ONE kernel, one workgroup per (batch, head), five MFMA products per score tile instead
+// of the seven of attn_bwd_dq_res_kernel + attn_bwd_dkdv_res_kernel (which both recompute S and dP), P = exp2(.) evaluated
+// once instead of twice, q | k | v | dO read once instead of twice.
+//
+// Decomposition (key-stationary, the structure of cdna_hip_programming.md 'Attention backward'):
+//   * NT waves; wave w owns keys 32 w .. 32 w + 31 for the whole kernel: their K / V fragments (B operands) and the fp32
+//     accumulators dK^T, dV^T [64 d][32 keys] live in registers (2 x 32 VGPRs) -- no sum across workgroups, no atomics;
+//   * Q and dO of the whole sequence sit in LDS (one image each serves row reads and transposed reads); the loop walks the
+//     NT + 1 query tiles of 32 rows (the last one holds the odd row T - 1 and 31 padding rows whose lse is +inf, so that
+//     their P and dS are exactly 0);
+//   * per query tile and wave, v_mfma_f32_32x32x16_bf16 with the KEY on the lane:
+//         S[q][key]  = Q . K^T              dP[q][key] = dO . V^T - delta[q]   (chain starts from -delta: no subtraction)
+//         P = exp2(c S - lse2[q])           dS = P dP
+//         dV^T[d][key] += dO^T . P          dK^T[d][key] += Q^T . dS           (the accumulator tile IS the B operand)
+//   * dQ sums over the keys, i.e. over the waves: every wave stores its dS tile (bf16, 2 KiB) to an LDS image
+//     [key][32 q], ONE barrier, then the 8 output tiles dQ^T[16 d][16 q] of the query tile are shared out over the waves,
+//     each a chain of v_mfma_f32_16x16x32_bf16 over all keys with A = K^T fragments held in registers for the whole kernel
+//     and B = transposed reads of the dS image; the image is double buffered, so the loop has one barrier per query tile;
+//   * the odd KEY (row T - 1) has no wave of its own: before the loop wave w takes query tile w against it (the same MFMAs
+//     with that key alone in column 0 of the B operands), leaves dS[q, T-1] in LDS -- a rank-1 term k_{T-1} dS[q, T-1] of
+//     every dQ tile -- and its share of that key's dK / dV rows, which meet in LDS.
+//
+// Arithmetic contract = that of the two-kernel path (tests/emulate.py): P and dS are rounded to bf16 where they enter a
+// product, everything else is fp32; delta = dO . O from the bf16 tensors; `scale` is applied once to dQ and dK.
+// Reference: softmax(q k^T hd^-0.5) v of timm's Attention (src/models/apf_utils.py:142-158), autograd of it.
+#pragma once
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// Q / dO images: 128-B rows, 16-B chunk' = chunk ^ sig(row).  sig uses row bits 1, 2 and 1^4: conflict-free for the 32-row
+// ds_read_b128 operand reads AND the 4-row-block transposed reads of the 32x32x16 products (searched with tools/lds_model.py;
+// the `row & 7` of the 64-row tiles above is 2-way on both).
+__device__ __forceinline__ int fz_sig(int row) { return ((row >> 1) & 3) | ((((row >> 1) ^ (row >> 4)) & 1) << 2); }
+// dS image: [key][32 q] bf16 = 64-B rows of eight 8-B slots, slot' = slot ^ sigd(key): conflict-free ds_write_b64 of a wave's
+// tile and conflict-free transposed reads of 8 consecutive keys.
+__device__ __forceinline__ int fz_sigd(int key) { return (((key >> 2) & 1) << 2) | (((key >> 3) & 1) << 1) | ((key >> 1) & 1); }
+
+// A operand of a 32x32x16 product: rows row0 .. row0 + 31 of an image, contraction columns 16 s .. 16 s + 15
+__device__ __forceinline__ bf16x8 fz_rows(const char* img, int row0, int s, int lane) {
+    const int row = row0 + (lane & 31);
+    return *reinterpret_cast<const bf16x8*>(img + row * 128 + (((2 * s + (lane >> 5)) ^ fz_sig(row)) << 4));
+}
+// A operand, transposed: output row = image column 32 dh + (lane & 31); contraction slot (h, j) = image row
+// row0 + 16 sp + 8 (j >> 2) + 4 h + (j & 3) -- the k order of registers 8 sp .. 8 sp + 7 of a 32x32 accumulator (guide section 3)
+__device__ __forceinline__ bf16x8 fz_tr(const char* img, int row0, int sp, int dh, int lane) {
+    const int G = lane >> 4, i = lane & 15;
+    const int row = row0 + 16 * sp + 4 * (G >> 1) + (i >> 2);       // bit 3 of the row is clear: row + 8 has the same sig
+    const int p = i & 3;
+    const int lch = 2 * (2 * dh + (G & 1)) + (p >> 1);
+    const char* a0 = img + row * 128 + ((lch ^ fz_sig(row)) << 4) + (p & 1) * 8;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 8 * 128));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+// B operand of the 16x16x32 dQ^T product from the dS image: column = query 16 a + (lane & 15); contraction slot (g, j) = key
+// 32 ks + 16 (j >> 2) + 4 g + (j & 3), the order frag_tr() gives the K^T fragments
+__device__ __forceinline__ bf16x8 fz_dst(const char* dsx, int ks, int a, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const int key = 32 * ks + 4 * g + (i >> 2), p = i & 3;           // bit 4 of the key is clear: key + 16 has the same sigd
+    const char* a0 = dsx + key * 64 + (((4 * a + p) ^ fz_sigd(key)) << 3);
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 16 * 64));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+// registers 8 sp .. 8 sp + 7 of a 32x32 accumulator as the bf16 B operand of the product that sums over its rows
+__device__ __forceinline__ void fz_pack(const f32x16& x, bf16x8 (&out)[2]) {
+#pragma unroll
+    for (int sp = 0; sp < 2; ++sp)
+        out[sp] = bf16x8{f2bf(x[8 * sp + 0]), f2bf(x[8 * sp + 1]), f2bf(x[8 * sp + 2]), f2bf(x[8 * sp + 3]),
+                         f2bf(x[8 * sp + 4]), f2bf(x[8 * sp + 5]), f2bf(x[8 * sp + 6]), f2bf(x[8 * sp + 7])};
+}
+// 16 per-row constants of query tile t in the accumulator layout: register 4 jj + r <-> row 8 jj + 4 h + r
+__device__ __forceinline__ f32x16 fz_rowconst(const float* arr, int row0, int lane) {
+    const int hh = lane >> 5;
+    f32x16 v;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(arr + row0 + 8 * jj + 4 * hh);
+        v[4 * jj + 0] = q[0]; v[4 * jj + 1] = q[1]; v[4 * jj + 2] = q[2]; v[4 * jj + 3] = q[3];
+    }
+    return v;
+}
+
+// Diagnostic build only (tools/attn_fused_stamps.py compiles attention.hip with -DP4P_FZ_STAMPS into its own library): s_memtime
+// stamps of wave 0 at the phase boundaries, written into the (otherwise unused) delta workspace.  No stamp in the product library.
+#ifdef P4P_FZ_STAMPS
+#define FZ_STAMP(k)                                                                                       \
+    do {                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        const unsigned long long ts_ = __builtin_readcyclecounter();                                      \
+        if (t == 0) reinterpret_cast<unsigned long long*>(p.delta)[(size_t)blockIdx.x * 16 + (k)] = ts_;   \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+    } while (0)
+#else
+#define FZ_STAMP(k) do { } while (0)
+#endif
+
+#define FZ_SLAB_STRIDE 272          // epilogue slab row: K 128 B | V 128 B | 16 B pad (bank spread of the 8-B writes)
+
+template <int NT>
+struct FzLds {
+    static constexpr int L = 32 * NT;                 // index of the odd row = number of tiled rows
+    static constexpr int ROWS = L + 32;               // rows of the Q / dO images (the last tile: row L + 31 padding rows)
+    static constexpr int IMG = ROWS * 128;
+    static constexpr int DSX = 2 * L * 64;            // two dS images; the K image of the prologue (L x 128 B) aliases them
+    static constexpr int OFF_Q = 0, OFF_DO = IMG, OFF_DSX = 2 * IMG;
+    static constexpr int OFF_NLSE = OFF_DSX + DSX;    // -lse2 [ROWS], -delta [ROWS], dS[q, L] scale [ROWS]
+    static constexpr int OFF_NDEL = OFF_NLSE + ROWS * 4;
+    static constexpr int OFF_DSL = OFF_NDEL + ROWS * 4;
+    static constexpr int OFF_PART = OFF_DSL + ROWS * 4;             // [NT][2][64] partial dK / dV rows of the odd key
+    static constexpr int OFF_LONE = OFF_PART + NT * 2 * 64 * 4;     // [2][64] its rounded dK / dV rows (column sums)
+    static constexpr int TOTAL = OFF_LONE + 2 * 64 * 4;
+    static_assert(2 * IMG >= NT * 32 * FZ_SLAB_STRIDE, "epilogue slabs must fit the Q / dO images");
+};
+
+template <int NT>
+__global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p) {
+    using LY = FzLds<NT>;
+    constexpr int L = LY::L, ROWS = LY::ROWS;
+    constexpr int TPW = 8 / NT;                       // dQ^T output tiles (16 d x 16 q) per wave and query tile
+    constexpr int NKS = L / 32;                       // 32-key contraction steps of the dQ product
+    static_assert(NT == 1 || NT == 2 || NT == 4 || NT == 8, "8 output tiles must divide over the waves");
+    __shared__ __attribute__((aligned(1024))) char lds[LY::TOTAL];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const int T = p.T, D = p.D;                       // T = L + 1
+    const size_t ld = (size_t)3 * D;
+    const __bf16* seq = p.qkv + (size_t)b * T * ld;
+    const __bf16* dob = p.dout + (size_t)b * T * D + h * HD;
+    const __bf16* ob = p.o + (size_t)b * T * D + h * HD;
+    const float c = p.scale * 1.4426950408889634f;
+    char* qs = lds + LY::OFF_Q;
+    char* dos = lds + LY::OFF_DO;
+    char* dsx = lds + LY::OFF_DSX;
+    float* nlse = reinterpret_cast<float*>(lds + LY::OFF_NLSE);
+    float* ndel = reinterpret_cast<float*>(lds + LY::OFF_NDEL);
+    float* dsl = reinterpret_cast<float*>(lds + LY::OFF_DSL);
+    float* part = reinterpret_cast<float*>(lds + LY::OFF_PART);
+    float* lonekv = reinterpret_cast<float*>(lds + LY::OFF_LONE);
+
+    FZ_STAMP(0);
+    // ---- stage Q, dO (1-KiB pieces of 8 rows; rows past L repeat row L) and K (64-row tiles, `row & 7` swizzle: frag_tr)
+    {
+        const int rin = lane >> 3;
+        constexpr int NPC = L / 8 + 1;                 // pieces per image: rows 0 .. L + 7
+        for (int pc = wave; pc < 2 * NPC; pc += NT) {
+            const int isd = pc >= NPC, piece = isd ? pc - NPC : pc;
+            const int row = piece * 8 + rin;
+            const int r = row < T ? row : T - 1;
+            const int chunk = (lane & 7) ^ fz_sig(row);
+            const __bf16* src = isd ? dob + (size_t)r * D + chunk * 8 : seq + (size_t)r * ld + h * HD + chunk * 8;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR((isd ? dos : qs) + piece * 1024), 16, 0, 0);
+        }
+        const int chunk = (lane & 7) ^ rin;
+        for (int pc = wave; pc < L / 8; pc += NT)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(seq + (size_t)(pc * 8 + rin) * ld + D + h * HD + chunk * 8),
+                                             LDS_PTR(dsx + pc * 1024), 16, 0, 0);
+        // rows L + 8 .. L + 31 of both images: zeros (finite operands for the padded rows of the last query tile)
+        for (int e = t; e < 2 * 24 * 8; e += NT * 64) {
+            char* img = e >= 24 * 8 ? dos : qs;
+            const int ee = e >= 24 * 8 ? e - 24 * 8 : e;
+            *reinterpret_cast<f32x4*>(img + (L + 8) * 128 + ee * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // ---- this wave's keys: K / V fragments (B operands of S and dP), straight from global memory
+    const int kk = lane & 31, hh = lane >> 5;
+    bf16x8 kf[4], vf[4];
+    {
+        const __bf16* krow = seq + (size_t)(32 * wave + kk) * ld + D + h * HD + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[s] = *reinterpret_cast<const bf16x8*>(krow + 16 * s);
+            vf[s] = *reinterpret_cast<const bf16x8*>(krow + D + 16 * s);
+        }
+    }
+    // ---- row statistics: -lse2, and -delta[q] = -(dO[q] . O[q]) over this head's 64 columns (wave w: rows 32 w ..; wave 0 also the odd row)
+    {
+        const float* lse_b = p.lse2 + ((size_t)b * p.H + h) * T;
+        for (int tw = wave; tw <= NT; tw += NT) {
+            const int row = 32 * tw + kk;
+            const int rc = row < T ? row : T - 1;      // every lane takes part in the half exchange below
+            const __bf16* orow = ob + (size_t)rc * D + 32 * hh;
+            const __bf16* drow = dob + (size_t)rc * D + 32 * hh;
+            float s = 0.f;
+#pragma unroll
+            for (int v8 = 0; v8 < 4; ++v8) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(orow + 8 * v8);
+                const bf16x8 d = *reinterpret_cast<const bf16x8*>(drow + 8 * v8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s = __builtin_fmaf(bf2f(a[j]), bf2f(d[j]), s);
+            }
+            float s2 = s;
+            lane_swap32(s, s2);                        // lanes l and l + 32 hold the two halves of one row
+            if (hh == 0) {                             // padding rows of the last tile: P = exp2(-inf) = 0
+                ndel[row] = row < T ? -(s + s2) : 0.f;
+                nlse[row] = row < T ? -lse_b[rc] : -INFINITY;
+            }
+        }
+    }
+    FZ_STAMP(1);
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __syncthreads();
+    FZ_STAMP(2);
+
+    // ---- K^T fragments of this wave's dQ^T output tiles (A operands, all keys), from the K image
+    bf16x8 ktf[TPW][NKS];
+#pragma unroll
+    for (int k = 0; k < TPW; ++k)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+            ktf[k][ks] = frag_tr(dsx + (ks >> 1) * TILE_BYTES, ks & 1, (wave + NT * k) & 3, lane);
+
+    // ---- the odd key (row L) against every query tile: column 0 of the B operands holds it, the other columns are zero
+    {
+        bf16x8 klf[4], vlf[4];
+        const __bf16* krow = seq + (size_t)L * ld + D + h * HD + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 z = {};
+            klf[s] = kk == 0 ? *reinterpret_cast<const bf16x8*>(krow + 16 * s) : z;
+            vlf[s] = kk == 0 ? *reinterpret_cast<const bf16x8*>(krow + D + 16 * s) : z;
+        }
+        f32x16 dkl[2], dvl[2];
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dkl[dh][r] = dvl[dh][r] = 0.f;
+        for (int tw = wave; tw <= NT; tw += NT) {
+            f32x16 s, dp = fz_rowconst(ndel, 32 * tw, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_rows(qs, 32 * tw, ks, lane), klf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_rows(dos, 32 * tw, ks, lane), vlf[ks], dp, 0, 0, 0);
+            }
+            const f32x16 nl = fz_rowconst(nlse, 32 * tw, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, nl[r]));
+                dp[r] = s[r] * dp[r];
+            }
+            bf16x8 pb[2], db[2];
+            fz_pack(s, pb);
+            fz_pack(dp, db);
+            if (kk == 0) {                            // dS[q, L] as the dQ product sees it (bf16), times scale
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    *reinterpret_cast<f32x4*>(dsl + 32 * tw + 8 * jj + 4 * hh) =
+                        f32x4{bf2f(f2bf(dp[4 * jj])), bf2f(f2bf(dp[4 * jj + 1])), bf2f(f2bf(dp[4 * jj + 2])), bf2f(f2bf(dp[4 * jj + 3]))} * p.scale;
+            }
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    dvl[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_tr(dos, 32 * tw, sp, dh, lane), pb[sp], dvl[dh], 0, 0, 0);
+                    dkl[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_tr(qs, 32 * tw, sp, dh, lane), db[sp], dkl[dh], 0, 0, 0);
+                }
+        }
+        if (kk == 0) {
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int d = 32 * dh + 8 * jj + 4 * hh;
+                    *reinterpret_cast<f32x4*>(part + (wave * 2 + 0) * 64 + d) = f32x4{dkl[dh][4 * jj], dkl[dh][4 * jj + 1], dkl[dh][4 * jj + 2], dkl[dh][4 * jj + 3]};
+                    *reinterpret_cast<f32x4*>(part + (wave * 2 + 1) * 64 + d) = f32x4{dvl[dh][4 * jj], dvl[dh][4 * jj + 1], dvl[dh][4 * jj + 2], dvl[dh][4 * jj + 3]};
+                }
+        }
+    }
+    FZ_STAMP(3);
+    __syncthreads();                                   // K image dead (ktf in registers), dsl / part visible
+    FZ_STAMP(4);
+    if (t < 128) {                                     // the odd key's dK / dV rows: fixed-order sum of the waves' partials
+        const int which = t >> 6, d = t & 63;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NT; ++w) v += part[(w * 2 + which) * 64 + d];
+        if (which == 0) v *= p.scale;
+        const __bf16 r = f2bf(v);
+        p.out[((size_t)b * T + L) * ld + (1 + which) * D + h * HD + d] = r;
+        lonekv[which * 64 + d] = bf2f(r);
+    }
+
+    // ---- main loop over the query tiles
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk[dh][r] = dv[dh][r] = 0.f;
+    f32x4 qsum[TPW];
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) qsum[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int i16 = lane & 15, g = lane >> 4;
+    for (int qt = 0; qt <= NT; ++qt) {
+        f32x16 s, dp = fz_rowconst(ndel, 32 * qt, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_rows(qs, 32 * qt, ks, lane), kf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_rows(dos, 32 * qt, ks, lane), vf[ks], dp, 0, 0, 0);
+        }
+        const f32x16 nl = fz_rowconst(nlse, 32 * qt, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, nl[r]));
+            dp[r] = s[r] * dp[r];
+        }
+        bf16x8 pb[2], db[2];
+        fz_pack(s, pb);
+        fz_pack(dp, db);
+        char* dsb = dsx + (qt & 1) * (L * 64);
+        {                                              // dS tile -> image [key][32 q]: registers 4 jj .. 4 jj + 3 = rows 8 jj + 4 h ..
+            const int key = 32 * wave + kk;
+            const u32x4 w0 = __builtin_bit_cast(u32x4, db[0]), w1 = __builtin_bit_cast(u32x4, db[1]);
+            const u32 words[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                *reinterpret_cast<u32x2*>(dsb + key * 64 + (((2 * jj + hh) ^ fz_sigd(key)) << 3)) = u32x2{words[2 * jj], words[2 * jj + 1]};
+        }
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                dv[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_tr(dos, 32 * qt, sp, dh, lane), pb[sp], dv[dh], 0, 0, 0);
+                dk[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_tr(qs, 32 * qt, sp, dh, lane), db[sp], dk[dh], 0, 0, 0);
+            }
+        __syncthreads();                               // every wave's dS tile of this query tile is in the image
+#pragma unroll
+        for (int k = 0; k < TPW; ++k) {
+            const int u = wave + NT * k, a = u >> 2, bq = u & 3;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[k][ks], fz_dst(dsb, ks, a, lane), acc, 0, 0, 0);
+            const int q = 32 * qt + 16 * a + i16;
+            // the odd key: k_L[d] dS[q, L] (dsl holds dS scale); d = 16 bq + 4 g + r
+            const bf16x4 kl = *reinterpret_cast<const bf16x4*>(seq + (size_t)L * ld + D + h * HD + 16 * bq + 4 * g);
+            const float dq_l = dsl[q];
+            if (q < T) {
+                bf16x4 w;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w[r] = f2bf(__builtin_fmaf(acc[r], p.scale, bf2f(kl[r]) * dq_l));
+                *reinterpret_cast<bf16x4*>(p.out + ((size_t)b * T + q) * ld + h * HD + 16 * bq + 4 * g) = w;
+                qsum[k] += f32x4{bf2f(w[0]), bf2f(w[1]), bf2f(w[2]), bf2f(w[3])};
+            }
+        }
+    }
+    FZ_STAMP(5);
+    __syncthreads();                                   // the last tile's transposed reads of Q / dO are done: the images become slabs
+
+    // ---- epilogue: dK, dV of this wave's 32 keys through a private LDS slab -> whole 128-B rows; column sums
+    {
+        char* slab = lds + wave * (32 * FZ_SLAB_STRIDE);
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int d = 32 * dh + 8 * jj + 4 * hh;
+                const bf16x4 wk = {f2bf(dk[dh][4 * jj] * p.scale), f2bf(dk[dh][4 * jj + 1] * p.scale), f2bf(dk[dh][4 * jj + 2] * p.scale),
+                                   f2bf(dk[dh][4 * jj + 3] * p.scale)};
+                const bf16x4 wv = {f2bf(dv[dh][4 * jj]), f2bf(dv[dh][4 * jj + 1]), f2bf(dv[dh][4 * jj + 2]), f2bf(dv[dh][4 * jj + 3])};
+                *reinterpret_cast<bf16x4*>(slab + kk * FZ_SLAB_STRIDE + d * 2) = wk;
+                *reinterpret_cast<bf16x4*>(slab + kk * FZ_SLAB_STRIDE + 128 + d * 2) = wv;
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the slab is wave-private, no barrier
+        {
+            const int key = lane >> 1, which = lane & 1;      // one lane = one 128-B row segment (dK or dV of one key)
+            const char* src = slab + key * FZ_SLAB_STRIDE + which * 128;
+            __bf16* dst = p.out + ((size_t)b * T + 32 * wave + key) * ld + (1 + which) * D + h * HD;
+#pragma unroll
+            for (int v8 = 0; v8 < 8; ++v8)
+                *reinterpret_cast<u32x4*>(dst + 8 * v8) = *reinterpret_cast<const u32x4*>(src + 16 * v8);
+        }
+        if (p.colsum) {
+            // column sums of the STORED (rounded) dq | dk | dv over this (b, h): partial row `wave` of RES_COLSUM_ROWS
+            float* row = p.colsum + ((size_t)b * RES_COLSUM_ROWS + wave) * ld + h * HD;
+            float s0 = 0.f, s1 = 0.f;                  // lane l: columns 2 l, 2 l + 1 of the slab's 128 (dK 64 | dV 64)
+            for (int key = 0; key < 32; ++key) {
+                const bf16x2 v = *reinterpret_cast<const bf16x2*>(slab + key * FZ_SLAB_STRIDE + 4 * lane);
+                s0 += bf2f(v[0]);
+                s1 += bf2f(v[1]);
+            }
+            const int which = lane >> 5, d = (2 * lane) & 63;
+            if (wave == 0) {                           // the odd key's rows
+                s0 += lonekv[which * 64 + d];
+                s1 += lonekv[which * 64 + d + 1];
+            }
+            *reinterpret_cast<f32x2*>(row + (1 + which) * D + d) = f32x2{s0, s1};
+            // dq: sum over the 16 queries of a lane row, then lane i16 == 0 holds the 4 columns 16 bq + 4 g ..; the other
+            // 48 columns of this partial row are zero (this wave did not produce them)
+            f32x4 red[TPW];
+#pragma unroll
+            for (int k = 0; k < TPW; ++k) {
+                red[k] = qsum[k];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = red[k][r];
+                    x += dpp_f32<0xB1>(x); x += dpp_f32<0x4E>(x); x += dpp_f32<0x141>(x); x += dpp_f32<0x140>(x);
+                    red[k][r] = x;
+                }
+            }
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < TPW; ++k)
+                    if (((wave + NT * k) & 3) == q4) z += red[k];      // wave-uniform; tiles with the same bq (a = 0, 1) add up
+                if (i16 == 0) *reinterpret_cast<f32x4*>(row + 16 * q4 + 4 * g) = z;
+            }
+            // partial rows NT .. 7 of this (b, h): zeros (the reducer sums RES_COLSUM_ROWS rows per sequence)
+            for (int e = lane; e < (RES_COLSUM_ROWS / NT - 1) * 3 * 16; e += 64) {
+                const int rr = e / 48, cc = e - rr * 48;
+                float* zr = p.colsum + ((size_t)b * RES_COLSUM_ROWS + wave + NT * (rr + 1)) * ld + h * HD + (cc >> 4) * D + (cc & 15) * 4;
+                *reinterpret_cast<f32x4*>(zr) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+    FZ_STAMP(6);
+}
