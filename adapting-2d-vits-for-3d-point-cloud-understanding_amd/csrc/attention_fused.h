@@ -287,7 +287,10 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
         lonekv[which * 64 + d] = bf2f(r);
     }
 
-    // ---- main loop over the query tiles
+    // ---- main loop over the query tiles.  The kernel is bound by instruction issue (~250 instructions per wave and tile in the
+    // first version, a third of them LDS address arithmetic), so the loop is fully unrolled and every LDS address is a
+    // lane-constant base register + an immediate: the swizzles' XORs only ever mix lane bits with lane bits, the
+    // compile-time parts (tile, k-step, half) are folded into which base is used and into the immediate.
     f32x16 dk[2], dv[2];
 #pragma unroll
     for (int dh = 0; dh < 2; ++dh)
@@ -297,16 +300,61 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
 #pragma unroll
     for (int k = 0; k < TPW; ++k) qsum[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int i16 = lane & 15, g = lane >> 4;
+    const int sg0 = fz_sig(kk);                                       // sig(row0 + kk) for any row0 % 32 == 0
+    const char* rowb[4];                                              // A operand rows: + row0 * 128 (+ IMG for dO)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rowb[ks] = qs + kk * 128 + (((2 * ks + hh) ^ sg0) << 4);
+    // transposed A operand: row = 16 sp + 4 hh + (i16 >> 2) (+ 8), chunk = (4 dh + 2 (g & 1) + (p >> 1)) ^ sig(row); bit 4 of the
+    // row (sp) flips bit 2 of sig, as dh flips bit 2 of the chunk: two bases, indexed by dh ^ sp
+    const char* trb[2];
+    {
+        const int rlo = 4 * hh + (i16 >> 2), pq = i16 & 3;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) trb[e] = qs + rlo * 128 + ((((2 * (g & 1) + (pq >> 1)) ^ fz_sig(rlo)) ^ (4 * e)) << 4) + (pq & 1) * 8;
+    }
+    auto tr32 = [&](int img_off, int row0, int sp, int dh) -> bf16x8 {
+        const char* a0 = trb[dh ^ sp] + img_off + row0 * 128 + sp * 2048;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 1024));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, r);
+    };
+    // dS image: write bases (4 slots of this lane's key), read bases (one per output tile's query half a)
+    const char* dswb[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) dswb[jj] = dsx + (32 * wave + kk) * 64 + (((2 * jj + hh) ^ fz_sigd(kk)) << 3);
+    const char* dstb[TPW];
+    bf16x4 klq[TPW];                                                  // the odd key's 4 columns of each output tile
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        const int u = wave + NT * k, a = u >> 2, bq = u & 3;
+        const int klo = 4 * g + (i16 >> 2);
+        dstb[k] = dsx + klo * 64 + (((4 * a + (i16 & 3)) ^ fz_sigd(klo)) << 3);
+        klq[k] = *reinterpret_cast<const bf16x4*>(seq + (size_t)L * ld + D + h * HD + 16 * bq + 4 * g);
+    }
+    const float* rcb = nlse + 4 * hh;                                 // row constants: + row0 + 8 jj (ndel: + ROWS)
+    auto rowconst = [&](int arr_off, int row0) -> f32x16 {
+        f32x16 v;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(rcb + arr_off + row0 + 8 * jj);
+            v[4 * jj + 0] = q[0]; v[4 * jj + 1] = q[1]; v[4 * jj + 2] = q[2]; v[4 * jj + 3] = q[3];
+        }
+        return v;
+    };
+#pragma unroll
     for (int qt = 0; qt <= NT; ++qt) {
-        f32x16 s, dp = fz_rowconst(ndel, 32 * qt, lane);
+        const int row0 = 32 * qt, boff = (qt & 1) * (L * 64);
+        f32x16 s, dp = rowconst(ROWS, row0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_rows(qs, 32 * qt, ks, lane), kf[ks], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_rows(dos, 32 * qt, ks, lane), vf[ks], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(rowb[ks] + row0 * 128), kf[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(rowb[ks] + LY::IMG + row0 * 128), vf[ks], dp, 0, 0, 0);
         }
-        const f32x16 nl = fz_rowconst(nlse, 32 * qt, lane);
+        const f32x16 nl = rowconst(0, row0);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, nl[r]));
@@ -315,21 +363,19 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
         bf16x8 pb[2], db[2];
         fz_pack(s, pb);
         fz_pack(dp, db);
-        char* dsb = dsx + (qt & 1) * (L * 64);
         {                                              // dS tile -> image [key][32 q]: registers 4 jj .. 4 jj + 3 = rows 8 jj + 4 h ..
-            const int key = 32 * wave + kk;
             const u32x4 w0 = __builtin_bit_cast(u32x4, db[0]), w1 = __builtin_bit_cast(u32x4, db[1]);
             const u32 words[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
-                *reinterpret_cast<u32x2*>(dsb + key * 64 + (((2 * jj + hh) ^ fz_sigd(key)) << 3)) = u32x2{words[2 * jj], words[2 * jj + 1]};
+                *reinterpret_cast<u32x2*>(const_cast<char*>(dswb[jj]) + boff) = u32x2{words[2 * jj], words[2 * jj + 1]};
         }
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
-                dv[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_tr(dos, 32 * qt, sp, dh, lane), pb[sp], dv[dh], 0, 0, 0);
-                dk[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_tr(qs, 32 * qt, sp, dh, lane), db[sp], dk[dh], 0, 0, 0);
+                dv[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr32(LY::IMG, row0, sp, dh), pb[sp], dv[dh], 0, 0, 0);
+                dk[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr32(0, row0, sp, dh), db[sp], dk[dh], 0, 0, 0);
             }
         __syncthreads();                               // every wave's dS tile of this query tile is in the image
 #pragma unroll
@@ -337,16 +383,20 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
             const int u = wave + NT * k, a = u >> 2, bq = u & 3;
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[k][ks], fz_dst(dsb, ks, a, lane), acc, 0, 0, 0);
-            const int q = 32 * qt + 16 * a + i16;
-            // the odd key: k_L[d] dS[q, L] (dsl holds dS scale); d = 16 bq + 4 g + r
-            const bf16x4 kl = *reinterpret_cast<const bf16x4*>(seq + (size_t)L * ld + D + h * HD + 16 * bq + 4 * g);
-            const float dq_l = dsl[q];
+            for (int ks = 0; ks < NKS; ++ks) {
+                const char* a0 = dstb[k] + boff + ks * 2048;
+                s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+                s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 1024));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                s16x8 r8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[k][ks], __builtin_bit_cast(bf16x8, r8), acc, 0, 0, 0);
+            }
+            const int q = row0 + 16 * a + i16;
+            const float dq_l = dsl[q];                 // the odd key: k_L[d] dS[q, L] (dsl holds dS scale); d = 16 bq + 4 g + r
             if (q < T) {
                 bf16x4 w;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) w[r] = f2bf(__builtin_fmaf(acc[r], p.scale, bf2f(kl[r]) * dq_l));
+                for (int r = 0; r < 4; ++r) w[r] = f2bf(__builtin_fmaf(acc[r], p.scale, bf2f(klq[k][r]) * dq_l));
                 *reinterpret_cast<bf16x4*>(p.out + ((size_t)b * T + q) * ld + h * HD + 16 * bq + 4 * g) = w;
                 qsum[k] += f32x4{bf2f(w[0]), bf2f(w[1]), bf2f(w[2]), bf2f(w[3])};
             }
