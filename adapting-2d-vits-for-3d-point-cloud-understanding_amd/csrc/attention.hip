@@ -1187,7 +1187,7 @@ __global__ __launch_bounds__(RES_DKDV_NW * 64, 2) void attn_bwd_dkdv_res_kernel(
 #include "attention_fused.h"
 
 // experiment switch for tools/attn_ab.py (in-process A/B, default 0 = automatic): bit 0 = no resident forward / dQ,
-// bit 1 = no resident dK/dV, bit 2 = no two-pass (64 n + 1) forward, bit 3 = no fused backward, bit 4 = persistent fused backward (experiment), bit 5 = no start shift.  Nothing in the product path sets it.
+// bit 1 = no resident dK/dV, bit 2 = no two-pass (64 n + 1) forward, bit 3 = no fused backward, bit 5 = no start shift of the fused backward.  Nothing in the product path sets it.
 static int g_attn_variant = 0;
 extern "C" int p4p_set_attention_variant(int v) { int o = g_attn_variant; g_attn_variant = v; return o; }
 
@@ -1270,18 +1270,8 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
             P4P_HIP(hipGetDevice(&dev));
             P4P_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
         }
-        if (g_attn_variant & 16) {                       // experiment: persistent form, one workgroup per CU walks its (b, h) pairs
-            const int bhn = B * H;
-            switch ((T - 1) / 32) {
-                case 2: hipLaunchKernelGGL(attn_bwd_fusedp_kernel<2>, dim3(bhn < 4 * ncu ? bhn : 4 * ncu), dim3(2 * 64), 0, st, p); break;
-                case 4: hipLaunchKernelGGL(attn_bwd_fusedp_kernel<4>, dim3(bhn < 2 * ncu ? bhn : 2 * ncu), dim3(4 * 64), 0, st, p); break;
-                default: hipLaunchKernelGGL(attn_bwd_fusedp_kernel<8>, dim3(bhn < ncu ? bhn : ncu), dim3(8 * 64), 0, st, p); break;
-            }
-            P4P_LAUNCH_CHECK();
-            return 0;
-        }
         const dim3 grid(B * H);
-        p.stagger_n = ncu; p.stagger_phases = 2; p.stagger_cycles = 14 * 1024;      // attention_fused.h: start-time shift of the first round
+        p.stagger_n = ncu; p.stagger_phases = 3; p.stagger_cycles = 10 * 1024;      // attention_fused.h: start-time shift of the first round
         if (g_attn_variant & 32) p.stagger_phases = 1;   // bit 5: no shift
         if (g_attn_variant >> 8) {                       // experiment: bits 8-9 phases - 1, bits 10.. shift in 1024-cycle units
             p.stagger_phases = ((g_attn_variant >> 8) & 3) + 1; p.stagger_cycles = (g_attn_variant >> 10) * 1024;

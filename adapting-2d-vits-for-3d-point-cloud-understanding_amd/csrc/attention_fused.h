@@ -112,8 +112,8 @@ struct FzLds {
     static constexpr int OFF_NLSE = OFF_DSX + DSX;    // -lse2 [ROWS], -delta [ROWS], dS[q, L] scale [ROWS]
     static constexpr int OFF_NDEL = OFF_NLSE + ROWS * 4;
     static constexpr int OFF_DSL = OFF_NDEL + ROWS * 4;
-    static constexpr int OFF_PART = OFF_DSL + ROWS * 4;             // [NT][2][64] partial dK / dV rows of the odd key
-    static constexpr int OFF_LONE = OFF_PART + NT * 2 * 64 * 4;     // [2][64] its rounded dK / dV rows (column sums)
+    static constexpr int OFF_PART = OFF_DSL + ROWS * 4;             // [NT + 1][2][64] partial dK / dV rows of the odd key (waves, then the pair (L, L))
+    static constexpr int OFF_LONE = OFF_PART + (NT + 1) * 2 * 64 * 4;   // [2][64] its rounded dK / dV rows (column sums)
     static constexpr int TOTAL = OFF_LONE + 2 * 64 * 4;
     static_assert(2 * IMG >= NT * 32 * FZ_SLAB_STRIDE, "epilogue slabs must fit the Q / dO images");
 };
@@ -145,8 +145,8 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
 
     // With one workgroup per CU and every workgroup alike, all CUs load at the same time and compute at the same time: the memory
     // system saturates, then idles.  The first round of workgroups therefore starts in `stagger_phases` groups `stagger_cycles`
-    // apart, and the rounds that follow inherit the shift (measured at B=256, H=12, T=257: 2 phases x 14k cycles 355 -> 340 us;
-    // 4 phases and longer shifts gain less, they pay more at the tail).
+    // apart, and the rounds that follow inherit the shift (measured at B=256, H=12, T=257, same call: no shift 316-337 us, 2 groups x
+    // 14k cycles 311, 3 x 10k 297, 3 x 7k 300, 4 x 5k / 4 x 8k 311-313: more groups pay more at the tail).
     if (p.stagger_phases > 1 && (int)blockIdx.x < p.stagger_n) {
         const int ph = blockIdx.x % p.stagger_phases;
         const unsigned long long t0 = __builtin_readcyclecounter();
@@ -186,16 +186,28 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
 #pragma unroll
         for (int s = 0; s < 4; ++s) vf[s] = *reinterpret_cast<const bf16x8*>(vrow + 16 * s);
     }
-    // ---- O rows of this wave's query tile(s) (wave w: rows 32 w ..; wave 0 also the odd row): delta needs them after the barrier
-    bf16x8 orow[2][4];
+    // ---- O rows of this wave's query tile (rows 32 w ..): delta needs them after the barrier
+    bf16x8 orow[4];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int tw = wave + e * NT;
-        if (tw <= NT) {                                 // (e = 1: wave 0 only)
-            const int row = 32 * tw + kk;
-            const int rc = row < T ? row : T - 1;
-#pragma unroll
-            for (int v8 = 0; v8 < 4; ++v8) orow[e][v8] = *reinterpret_cast<const bf16x8*>(ob + (size_t)rc * D + 32 * hh + 8 * v8);
+    for (int v8 = 0; v8 < 4; ++v8) orow[v8] = *reinterpret_cast<const bf16x8*>(ob + (size_t)(32 * wave + kk) * D + 32 * hh + 8 * v8);
+    // ---- the odd row against itself, and its statistics: five 64-vectors, one column per lane of wave 0 (the pair (L, L) is the
+    // only part of the last query tile's column of the odd key that is not padding: no MFMA tile for it)
+    if (wave == 0) {
+        const size_t rl = (size_t)L * ld + h * HD + lane;
+        const float ql = bf2f(seq[rl]), kl = bf2f(seq[rl + D]), vl = bf2f(seq[rl + 2 * D]);
+        const float dol = bf2f(dob[(size_t)L * D + lane]), ol = bf2f(ob[(size_t)L * D + lane]);
+        const float lse_l = p.lse2[((size_t)b * p.H + h) * T + L];
+        const float dl = wave_sum_f32(ol * dol);
+        const float sl = wave_sum_f32(ql * kl);
+        const float dpl = wave_sum_f32(dol * vl) - dl;
+        const float pl = __builtin_amdgcn_exp2f(__builtin_fmaf(sl, c, -lse_l));
+        const float pr = bf2f(f2bf(pl)), dsr = bf2f(f2bf(pl * dpl));     // as the products see them
+        part[(NT * 2 + 0) * 64 + lane] = dsr * ql;                       // the pair's share of dK[L], dV[L]
+        part[(NT * 2 + 1) * 64 + lane] = pr * dol;
+        if (lane < 32) {                               // rows L .. L + 31: the odd row, then padding (P = exp2(-inf) = 0)
+            nlse[L + lane] = lane == 0 ? -lse_l : -INFINITY;
+            ndel[L + lane] = lane == 0 ? -dl : 0.f;
+            dsl[L + lane] = lane == 0 ? dsr * p.scale : 0.f;
         }
     }
     FZ_STAMP(1);
@@ -209,28 +221,21 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
 #pragma unroll
         for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const bf16x8*>(krow + (((2 * s + hh) ^ (key & 7)) << 4));
     }
-    // ---- row statistics: -lse2, and -delta[q] = -(dO[q] . O[q]) over this head's 64 columns, dO from its image
+    // ---- row statistics of this wave's query tile: -lse2, and -delta[q] = -(dO[q] . O[q]) over this head's 64 columns, dO from its image
     {
-        const float* lse_b = p.lse2 + ((size_t)b * p.H + h) * T;
+        const int row = 32 * wave + kk;
+        float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int tw = wave + e * NT;
-            if (tw <= NT) {
-                const int row = 32 * tw + kk;
-                float s = 0.f;
+        for (int v8 = 0; v8 < 4; ++v8) {
+            const bf16x8 d = *reinterpret_cast<const bf16x8*>(dos + row * 128 + (((4 * hh + v8) ^ fz_sig(row)) << 4));
 #pragma unroll
-                for (int v8 = 0; v8 < 4; ++v8) {
-                    const bf16x8 d = *reinterpret_cast<const bf16x8*>(dos + row * 128 + (((4 * hh + v8) ^ fz_sig(row)) << 4));
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) s = __builtin_fmaf(bf2f(orow[e][v8][j]), bf2f(d[j]), s);
-                }
-                float s2 = s;
-                lane_swap32(s, s2);                    // lanes l and l + 32 hold the two halves of one row (all lanes take part)
-                if (hh == 0) {                         // padding rows of the last tile: P = exp2(-inf) = 0
-                    ndel[row] = row < T ? -(s + s2) : 0.f;
-                    nlse[row] = row < T ? -lse_b[row < T ? row : T - 1] : -INFINITY;
-                }
-            }
+            for (int j = 0; j < 8; ++j) s = __builtin_fmaf(bf2f(orow[v8][j]), bf2f(d[j]), s);
+        }
+        float s2 = s;
+        lane_swap32(s, s2);                            // lanes l and l + 32 hold the two halves of one row
+        if (hh == 0) {
+            ndel[row] = -(s + s2);
+            nlse[row] = -p.lse2[((size_t)b * p.H + h) * T + row];
         }
     }
 
@@ -257,7 +262,8 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
         for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dkl[dh][r] = dvl[dh][r] = 0.f;
-        for (int tw = wave; tw <= NT; tw += NT) {
+        {
+            const int tw = wave;                       // (the pair (L, L) of the last query tile: wave 0's scalars above)
             f32x16 s, dp = fz_rowconst(ndel, 32 * tw, lane);
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
         const int which = t >> 6, d = t & 63;
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < NT; ++w) v += part[(w * 2 + which) * 64 + d];
+        for (int w = 0; w <= NT; ++w) v += part[(w * 2 + which) * 64 + d];
         if (which == 0) v *= p.scale;
         const __bf16 r = f2bf(v);
         p.out[((size_t)b * T + L) * ld + (1 + which) * D + h * HD + d] = r;
@@ -502,480 +508,11 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
     FZ_STAMP(6);
 }
 
-// ================================================================================================================================
-// The same backward as a PERSISTENT kernel: one workgroup per CU walks its (batch, head) pairs, and the next pair's operands are
-// fetched while the current pair computes.  The stamps of attn_bwd_fused_kernel (tools/attn_fused_stamps.py) put 52 % of a
-// workgroup's life in its load phase: ~200 KB per pair at a 1/256 share of the memory system, with every CU loading at the same
-// time and the memory system idle while they all compute -- at one workgroup per CU (LDS) nothing else overlaps the two.  Here
-//   * Q / dO tile j of the NEXT pair is loaded into registers two query tiles ahead (16 B per lane and tile: no LDS-DMA in the
-//     steady state -- hipcc drains vmcnt(0) in front of every LDS read while a DMA is outstanding) and written over tile j of the
-//     images once the current pair is done with it (after the barrier of iteration j); the waves that carry dO chunks also carry
-//     the matching O chunks and leave -delta = -(dO . O) per row, the others -lse2, in the other half of a double-buffered table;
-//   * the next pair's K / V fragments replace the current ones right after their last use (the scores of the last tile), its K
-//     image (for the K^T fragments) waits in registers across the epilogue and goes into the dS buffers after it.
-// What stays exposed per pair: the odd key's phase and the epilogue.
-template <int NT>
-struct FpLds {
-    static constexpr int L = 32 * NT, ROWS = L + 32, IMG = ROWS * 128;
-    static constexpr int DSX = 2 * L * 64;
-    static constexpr int SLAB_STRIDE = 144;           // 32 keys x (128 B + 16): one tensor (dK, then dV) per pass, wave-private
-    static constexpr int SLAB = NT * 32 * SLAB_STRIDE;
-    static constexpr int OFF_Q = 0, OFF_DO = IMG, OFF_DSX = 2 * IMG, OFF_SLAB = OFF_DSX + DSX;
-    static constexpr int OFF_STAT = OFF_SLAB + SLAB;  // [2 pairs in flight][-lse2 [ROWS] | -delta [ROWS]]
-    static constexpr int OFF_DSL = OFF_STAT + 2 * 2 * ROWS * 4;
-    static constexpr int OFF_PART = OFF_DSL + ROWS * 4;
-    static constexpr int OFF_LONE = OFF_PART + NT * 2 * 64 * 4;
-    static constexpr int TOTAL = OFF_LONE + 2 * 64 * 4;
-    static_assert(TOTAL <= 160 * 1024, "LDS");
-};
-
-template <int NT>
-__global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fusedp_kernel(AttnParams p) {
-    using LY = FpLds<NT>;
-    constexpr int L = LY::L, ROWS = LY::ROWS;
-    constexpr int TPW = 8 / NT;                       // dQ^T output tiles per wave and query tile = staged 1-KiB pieces per wave and tile
-    constexpr int NKS = L / 32;
-    constexpr int KPW = (L / 8) / NT;                 // K-image pieces per wave (4)
-    static_assert(NT == 2 || NT == 4 || NT == 8, "8 output tiles / pieces must divide over the waves");
-    __shared__ __attribute__((aligned(1024))) char lds[LY::TOTAL];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int T = p.T, D = p.D, H = p.H;              // T = L + 1
-    const int BH = p.B * H, stride = gridDim.x;
-    const size_t ld = (size_t)3 * D;
-    const float c = p.scale * 1.4426950408889634f;
-    char* qs = lds + LY::OFF_Q;
-    char* dos = lds + LY::OFF_DO;
-    char* dsx = lds + LY::OFF_DSX;
-    char* kimg = dsx;                                  // a pair's K image sits in the dS buffers until its K^T fragments are read
-    float* statb = reinterpret_cast<float*>(lds + LY::OFF_STAT);
-    float* dsl = reinterpret_cast<float*>(lds + LY::OFF_DSL);
-    float* part = reinterpret_cast<float*>(lds + LY::OFF_PART);
-    float* lonekv = reinterpret_cast<float*>(lds + LY::OFF_LONE);
-    const int kk = lane & 31, hh = lane >> 5, i16 = lane & 15, g = lane >> 4, rin = lane >> 3;
-
-    // ---- lane-constant LDS bases (see attn_bwd_fused_kernel)
-    const char* rowb[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) rowb[ks] = qs + kk * 128 + (((2 * ks + hh) ^ fz_sig(kk)) << 4);
-    const char* trb[2];
-    {
-        const int rlo = 4 * hh + (i16 >> 2), pq = i16 & 3;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) trb[e] = qs + rlo * 128 + ((((2 * (g & 1) + (pq >> 1)) ^ fz_sig(rlo)) ^ (4 * e)) << 4) + (pq & 1) * 8;
-    }
-    auto tr32 = [&](int img_off, int row0, int sp, int dh) -> bf16x8 {
-        const char* a0 = trb[dh ^ sp] + img_off + row0 * 128 + sp * 2048;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 1024));
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        return __builtin_bit_cast(bf16x8, r);
-    };
-    char* dswb[4];
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) dswb[jj] = dsx + (32 * wave + kk) * 64 + (((2 * jj + hh) ^ fz_sigd(kk)) << 3);
-    const char* dstb[TPW];
-#pragma unroll
-    for (int k = 0; k < TPW; ++k) {
-        const int a = (wave + NT * k) >> 2, klo = 4 * g + (i16 >> 2);
-        dstb[k] = dsx + klo * 64 + (((4 * a + (i16 & 3)) ^ fz_sigd(klo)) << 3);
-    }
-    // staged pieces: piece pc = wave + NT k of a tile: image pc >> 2 (0 = Q, 1 = dO), rows 8 (pc & 3) + rin of the tile
-    int pc_isd[TPW], pc_pi[TPW], pc_chunk[TPW];
-#pragma unroll
-    for (int k = 0; k < TPW; ++k) {
-        const int pc = wave + NT * k;
-        pc_isd[k] = pc >> 2;
-        pc_pi[k] = pc & 3;
-        pc_chunk[k] = (lane & 7) ^ fz_sig(8 * pc_pi[k] + rin);          // source chunk of LDS chunk lane & 7 (sig: row bits 1, 2, 4)
-    }
-
-    // global addresses = wave-uniform base (SGPRs, advanced per pair / tile) + a lane-constant 32-bit byte offset
-    u32 pc_voff[TPW];                                  // staged piece: its lane's row and source chunk inside a tile
-    int pc_srow[TPW];                                  // ... its row of the tile (statistics tables), its LDS destination in tile 0
-    char* pc_dst[TPW];
-#pragma unroll
-    for (int k = 0; k < TPW; ++k) {
-        pc_voff[k] = (u32)((8 * pc_pi[k] + rin) * (pc_isd[k] ? D : (int)ld) * 2 + pc_chunk[k] * 16);
-        pc_srow[k] = 8 * pc_pi[k] + rin;
-        pc_dst[k] = (pc_isd[k] ? dos : qs) + pc_pi[k] * 1024 + lane * 16;
-    }
-    // (offsets used once per pair -- K-image pieces, K / V fragment rows, epilogue rows -- are computed where they are used)
-    u32 dq_voff[TPW];                                  // dQ^T tile stores: row 16 a + i16 of the query tile, columns 16 bq + 4 g ..
-#pragma unroll
-    for (int k = 0; k < TPW; ++k) {
-        const int u = wave + NT * k;
-        dq_voff[k] = (u32)((16 * (u >> 2) + i16) * (int)ld * 2 + (16 * (u & 3) + 4 * g) * 2);
-    }
-
-    // ---- once per workgroup: the zero rows of the images, the padding rows of both statistics tables
-    for (int e = t; e < 2 * 24 * 8; e += NT * 64) {
-        char* img = e >= 24 * 8 ? dos : qs;
-        const int ee = e >= 24 * 8 ? e - 24 * 8 : e;
-        *reinterpret_cast<f32x4*>(img + (L + 8) * 128 + ee * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    for (int e = t; e < 2 * 31; e += NT * 64) {
-        float* st = statb + (e / 31) * 2 * ROWS;
-        st[L + 1 + e % 31] = -INFINITY;               // lse2 = +inf: P = 0 on the padded rows of the last query tile
-        st[ROWS + L + 1 + e % 31] = 0.f;
-    }
-
-    int bh = blockIdx.x;
-    bf16x8 kf[4], vf[4];
-    // ---- first pair: LDS-DMA of Q, dO, K; fragments and statistics as in attn_bwd_fused_kernel
-    {
-        const int b = bh / H, h = bh - b * H;
-        const __bf16* seq = p.qkv + (size_t)b * T * ld;
-        const __bf16* dob = p.dout + (size_t)b * T * D + h * HD;
-        const __bf16* ob = p.o + (size_t)b * T * D + h * HD;
-        constexpr int NPC = L / 8 + 1;
-        for (int pc = wave; pc < 2 * NPC; pc += NT) {
-            const int isd = pc >= NPC, piece = isd ? pc - NPC : pc;
-            const int row = piece * 8 + rin;
-            const int r = row < T ? row : T - 1;
-            const int chunk = (lane & 7) ^ fz_sig(row);
-            const __bf16* src = isd ? dob + (size_t)r * D + chunk * 8 : seq + (size_t)r * ld + h * HD + chunk * 8;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR((isd ? dos : qs) + piece * 1024), 16, 0, 0);
-        }
-        for (int pc = wave; pc < L / 8; pc += NT)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(seq + (size_t)(pc * 8 + rin) * ld + D + h * HD + ((lane & 7) ^ rin) * 8),
-                                             LDS_PTR(kimg + pc * 1024), 16, 0, 0);
-        const __bf16* krow = seq + (size_t)(32 * wave + kk) * ld + D + h * HD + 8 * hh;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            kf[s] = *reinterpret_cast<const bf16x8*>(krow + 16 * s);
-            vf[s] = *reinterpret_cast<const bf16x8*>(krow + D + 16 * s);
-        }
-        const float* lse_b = p.lse2 + (size_t)bh * T;
-        for (int tw = wave; tw <= NT; tw += NT) {
-            const int row = 32 * tw + kk;
-            const int rc = row < T ? row : T - 1;
-            const __bf16* orow = ob + (size_t)rc * D + 32 * hh;
-            const __bf16* drow = dob + (size_t)rc * D + 32 * hh;
-            float s = 0.f;
-#pragma unroll
-            for (int v8 = 0; v8 < 4; ++v8) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(orow + 8 * v8);
-                const bf16x8 d = *reinterpret_cast<const bf16x8*>(drow + 8 * v8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s = __builtin_fmaf(bf2f(a[j]), bf2f(d[j]), s);
-            }
-            float s2 = s;
-            lane_swap32(s, s2);
-            if (hh == 0 && row < T) {
-                statb[ROWS + row] = -(s + s2);
-                statb[row] = -lse_b[rc];
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0x0070);
-        __syncthreads();
-    }
-
-    for (int n = 0;; ++n) {
-        const int b = bh / H, h = bh - b * H;
-        const __bf16* seq = p.qkv + (size_t)b * T * ld;
-        const bool has_next = bh + stride < BH;
-        const int bhn = has_next ? bh + stride : bh;                   // (clamped: the pointers below stay valid, unused)
-        const int bn = bhn / H, hn = bhn - bn * H;
-        const __bf16* seqn = p.qkv + (size_t)bn * T * ld;
-        const __bf16* dobn = p.dout + (size_t)bn * T * D + hn * HD;
-        const __bf16* obn = p.o + (size_t)bn * T * D + hn * HD;
-        const float* lsen = p.lse2 + (size_t)bhn * T;
-        float* stat = statb + (n & 1) * 2 * ROWS;                       // this pair's -lse2 | -delta
-        float* statn = statb + ((n + 1) & 1) * 2 * ROWS;
-        const float* rcb = stat + 4 * hh;
-        auto rowconst = [&](int arr_off, int row0) -> f32x16 {
-            f32x16 v;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(rcb + arr_off + row0 + 8 * jj);
-                v[4 * jj + 0] = q[0]; v[4 * jj + 1] = q[1]; v[4 * jj + 2] = q[2]; v[4 * jj + 3] = q[3];
-            }
-            return v;
-        };
-        // ---- next pair's tiles: registers two tiles ahead (set j & 1), committed after the barrier of iteration j
-        u32x4 stg[2][TPW], sto[2][TPW];
-        float stl[2][TPW];
-        const char* gq = reinterpret_cast<const char*>(seqn + hn * HD);        // next pair: q rows, dO rows, O rows of this head
-        const char* gd = reinterpret_cast<const char*>(dobn);
-        const char* go = reinterpret_cast<const char*>(obn);
-        auto stage = [&](int j) {                      // j compile-time after unrolling
-#pragma unroll
-            for (int k = 0; k < TPW; ++k) {
-                if (j == NT && pc_pi[k] != 0) continue;                // rows L + 8 ..: the zero rows
-                // the last tile: every row of the piece is row L (rows past it are copies; their statistics say P = 0)
-                const u32 vo = j == NT ? (u32)(pc_chunk[k] * 16) : pc_voff[k];
-                if (pc_isd[k]) {
-                    stg[j & 1][k] = *reinterpret_cast<const u32x4*>(gd + (size_t)(32 * j) * D * 2 + vo);
-                    sto[j & 1][k] = *reinterpret_cast<const u32x4*>(go + (size_t)(32 * j) * D * 2 + vo);
-                } else {
-                    stg[j & 1][k] = *reinterpret_cast<const u32x4*>(gq + (size_t)(32 * j) * ld * 2 + vo);
-                    stl[j & 1][k] = j == NT ? lsen[L] : lsen[32 * j + pc_srow[k]];
-                }
-            }
-        };
-        auto commit = [&](int j) {
-#pragma unroll
-            for (int k = 0; k < TPW; ++k) {
-                if (j == NT && pc_pi[k] != 0) continue;
-                *reinterpret_cast<u32x4*>(pc_dst[k] + 32 * j * 128) = stg[j & 1][k];
-                const bool writer = j == NT ? lane == 0 : (lane & 7) == 0;       // one lane per row (the last tile: row L alone)
-                if (pc_isd[k]) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, sto[j & 1][k]), d = __builtin_bit_cast(bf16x8, stg[j & 1][k]);
-                    float s = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) s = __builtin_fmaf(bf2f(a[e]), bf2f(d[e]), s);
-                    s += dpp_f32<0xB1>(s); s += dpp_f32<0x4E>(s); s += dpp_f32<0x141>(s);      // the 8 lanes of a row
-                    if (writer) statn[ROWS + 32 * j + pc_srow[k]] = -s;
-                } else if (writer) {
-                    statn[32 * j + pc_srow[k]] = -stl[j & 1][k];
-                }
-            }
-        };
-
-        if (has_next) stage(0);
-        // ---- the odd key (row L) against every query tile (attn_bwd_fused_kernel)
-        {
-            bf16x8 klf[4], vlf[4];
-            const __bf16* krow = seq + (size_t)L * ld + D + h * HD + 8 * hh;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const bf16x8 z = {};
-                klf[s] = kk == 0 ? *reinterpret_cast<const bf16x8*>(krow + 16 * s) : z;
-                vlf[s] = kk == 0 ? *reinterpret_cast<const bf16x8*>(krow + D + 16 * s) : z;
-            }
-            f32x16 dkl[2], dvl[2];
-#pragma unroll
-            for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dkl[dh][r] = dvl[dh][r] = 0.f;
-            for (int tw = wave; tw <= NT; tw += NT) {
-                f32x16 s, dp = fz_rowconst(stat + ROWS, 32 * tw, lane);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_rows(qs, 32 * tw, ks, lane), klf[ks], s, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_rows(dos, 32 * tw, ks, lane), vlf[ks], dp, 0, 0, 0);
-                }
-                const f32x16 nl = fz_rowconst(stat, 32 * tw, lane);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, nl[r]));
-                    dp[r] = s[r] * dp[r];
-                }
-                bf16x8 pb[2], db[2];
-                fz_pack(s, pb);
-                fz_pack(dp, db);
-                if (kk == 0) {
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-                        *reinterpret_cast<f32x4*>(dsl + 32 * tw + 8 * jj + 4 * hh) =
-                            f32x4{bf2f(f2bf(dp[4 * jj])), bf2f(f2bf(dp[4 * jj + 1])), bf2f(f2bf(dp[4 * jj + 2])), bf2f(f2bf(dp[4 * jj + 3]))} * p.scale;
-                }
-#pragma unroll
-                for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-                    for (int sp = 0; sp < 2; ++sp) {
-                        dvl[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_tr(dos, 32 * tw, sp, dh, lane), pb[sp], dvl[dh], 0, 0, 0);
-                        dkl[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fz_tr(qs, 32 * tw, sp, dh, lane), db[sp], dkl[dh], 0, 0, 0);
-                    }
-            }
-            if (kk == 0) {
-#pragma unroll
-                for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const int d = 32 * dh + 8 * jj + 4 * hh;
-                        *reinterpret_cast<f32x4*>(part + (wave * 2 + 0) * 64 + d) = f32x4{dkl[dh][4 * jj], dkl[dh][4 * jj + 1], dkl[dh][4 * jj + 2], dkl[dh][4 * jj + 3]};
-                        *reinterpret_cast<f32x4*>(part + (wave * 2 + 1) * 64 + d) = f32x4{dvl[dh][4 * jj], dvl[dh][4 * jj + 1], dvl[dh][4 * jj + 2], dvl[dh][4 * jj + 3]};
-                    }
-            }
-        }
-        // ---- (after the odd key's phase: 32 registers fewer during it) K^T fragments of this wave's dQ^T tiles (A operands, all keys) from the K image; the odd key's columns
-        bf16x8 ktf[TPW][NKS];
-        bf16x4 klq[TPW];
-#pragma unroll
-        for (int k = 0; k < TPW; ++k) {
-            const int bq = (wave + NT * k) & 3;
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) ktf[k][ks] = frag_tr(kimg + (ks >> 1) * TILE_BYTES, ks & 1, bq, lane);
-            klq[k] = *reinterpret_cast<const bf16x4*>(seq + (size_t)L * ld + D + h * HD + 16 * bq + 4 * g);
-        }
-        __syncthreads();                               // K image read by every wave (the dS buffers are free), dsl / part visible
-        if (t < 128) {
-            const int which = t >> 6, d = t & 63;
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < NT; ++w) v += part[(w * 2 + which) * 64 + d];
-            if (which == 0) v *= p.scale;
-            const __bf16 r = f2bf(v);
-            p.out[((size_t)b * T + L) * ld + (1 + which) * D + h * HD + d] = r;
-            lonekv[which * 64 + d] = bf2f(r);
-        }
-
-        // ---- the query tiles
-        f32x16 dk[2], dv[2];
-#pragma unroll
-        for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dk[dh][r] = dv[dh][r] = 0.f;
-        f32x4 qsum[TPW];
-#pragma unroll
-        for (int k = 0; k < TPW; ++k) qsum[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int qt = 0; qt <= NT; ++qt) {
-            const int row0 = 32 * qt, boff = (qt & 1) * (L * 64);
-            if (has_next) {                            // tile j is requested in iteration j - 1 and written in iteration j + 1
-                if (qt > 0) commit(qt - 1);
-                if (qt < NT) stage(qt + 1);
-            }
-            f32x16 s, dp = rowconst(ROWS, row0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(rowb[ks] + row0 * 128), kf[ks], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(rowb[ks] + LY::IMG + row0 * 128), vf[ks], dp, 0, 0, 0);
-            }
-            if (qt == NT && has_next) {                // the next pair's K / V fragments over the current ones (last use: above)
-                const char* krow = reinterpret_cast<const char*>(seqn + D + hn * HD) + (u32)((32 * wave + kk) * (int)ld * 2 + 16 * hh);
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    kf[s4] = *reinterpret_cast<const bf16x8*>(krow + 32 * s4);
-                    vf[s4] = *reinterpret_cast<const bf16x8*>(krow + D * 2 + 32 * s4);
-                }
-            }
-            const f32x16 nl = rowconst(0, row0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, nl[r]));
-                dp[r] = s[r] * dp[r];
-            }
-            bf16x8 pb[2], db[2];
-            fz_pack(s, pb);
-            fz_pack(dp, db);
-            {
-                const u32x4 w0 = __builtin_bit_cast(u32x4, db[0]), w1 = __builtin_bit_cast(u32x4, db[1]);
-                const u32 words[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) *reinterpret_cast<u32x2*>(dswb[jj] + boff) = u32x2{words[2 * jj], words[2 * jj + 1]};
-            }
-#pragma unroll
-            for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
-                    dv[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr32(LY::IMG, row0, sp, dh), pb[sp], dv[dh], 0, 0, 0);
-                    dk[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr32(0, row0, sp, dh), db[sp], dk[dh], 0, 0, 0);
-                }
-            __syncthreads();                           // every wave's dS tile of this query tile is in the image
-#pragma unroll
-            for (int k = 0; k < TPW; ++k) {
-                const int u = wave + NT * k, a = u >> 2, bq = u & 3;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    const char* a0 = dstb[k] + boff + ks * 2048;
-                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 1024));
-                    typedef __attribute__((ext_vector_type(8))) short s16x8;
-                    s16x8 r8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[k][ks], __builtin_bit_cast(bf16x8, r8), acc, 0, 0, 0);
-                }
-                const int q = row0 + 16 * a + i16;
-                const float dq_l = dsl[q];
-                if (q < T) {
-                    bf16x4 w;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) w[r] = f2bf(__builtin_fmaf(acc[r], p.scale, bf2f(klq[k][r]) * dq_l));
-                    *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(p.out + ((size_t)b * T + row0) * ld + h * HD) + dq_voff[k]) = w;
-                    qsum[k] += f32x4{bf2f(w[0]), bf2f(w[1]), bf2f(w[2]), bf2f(w[3])};
-                }
-            }
-        }
-        // ---- the next pair's K image: into registers before the epilogue, into the dS buffers after it
-        u32x4 kst[KPW];
-        if (has_next) {
-#pragma unroll
-            for (int k2 = 0; k2 < KPW; ++k2)
-                kst[k2] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(seqn + D + hn * HD) + (u32)(((wave + NT * k2) * 8 + rin) * (int)ld * 2 + ((lane & 7) ^ rin) * 16));
-        }
-        __syncthreads();                               // the last tile's reads of the images and of the dS buffer are done
-        if (has_next) commit(NT);
-
-        // ---- epilogue: dK, then dV of this wave's 32 keys through its slab -> whole 128-B rows; column sums of what is stored
-        {
-            char* slab = lds + LY::OFF_SLAB + wave * (32 * LY::SLAB_STRIDE);
-            float* crow = p.colsum ? p.colsum + ((size_t)b * RES_COLSUM_ROWS + wave) * ld + h * HD : nullptr;
-#pragma unroll
-            for (int which = 0; which < 2; ++which) {
-#pragma unroll
-                for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const float sc = which == 0 ? p.scale : 1.0f;
-                        const f32x16& x = which == 0 ? dk[dh] : dv[dh];
-                        const bf16x4 w = {f2bf(x[4 * jj] * sc), f2bf(x[4 * jj + 1] * sc), f2bf(x[4 * jj + 2] * sc), f2bf(x[4 * jj + 3] * sc)};
-                        *reinterpret_cast<bf16x4*>(slab + kk * LY::SLAB_STRIDE + (32 * dh + 8 * jj + 4 * hh) * 2) = w;
-                    }
-                {
-                    const int key = lane >> 1, half = lane & 1;          // two lanes = one 128-B row
-                    const char* src = slab + key * LY::SLAB_STRIDE + half * 64;
-                    char* dst = reinterpret_cast<char*>(p.out + (size_t)b * T * ld + (1 + which) * D + h * HD) + (u32)((32 * wave + key) * (int)ld * 2 + 64 * half);
-#pragma unroll
-                    for (int v8 = 0; v8 < 4; ++v8) *reinterpret_cast<u32x4*>(dst + 16 * v8) = *reinterpret_cast<const u32x4*>(src + 16 * v8);
-                }
-                if (crow) {                                // lane l: columns 2 (l & 31) .., keys 16 (l >> 5) ..: halves meet by a lane swap
-                    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                    for (int key = 0; key < 16; ++key) {
-                        const bf16x2 v = *reinterpret_cast<const bf16x2*>(slab + (16 * hh + key) * LY::SLAB_STRIDE + 4 * kk);
-                        s0 += bf2f(v[0]);
-                        s1 += bf2f(v[1]);
-                    }
-                    float a0 = s0, a1 = s0, b0 = s1, b1 = s1;
-                    lane_swap32(a0, a1);
-                    lane_swap32(b0, b1);
-                    s0 = a0 + a1;
-                    s1 = b0 + b1;
-                    if (wave == 0) {                       // the odd key's rows
-                        s0 += lonekv[which * 64 + 2 * kk];
-                        s1 += lonekv[which * 64 + 2 * kk + 1];
-                    }
-                    if (hh == 0) *reinterpret_cast<f32x2*>(crow + (1 + which) * D + 2 * kk) = f32x2{s0, s1};
-                }
-            }
-            if (crow) {
-                f32x4 red[TPW];
-#pragma unroll
-                for (int k = 0; k < TPW; ++k) {
-                    red[k] = qsum[k];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float x = red[k][r];
-                        x += dpp_f32<0xB1>(x); x += dpp_f32<0x4E>(x); x += dpp_f32<0x141>(x); x += dpp_f32<0x140>(x);
-                        red[k][r] = x;
-                    }
-                }
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int k = 0; k < TPW; ++k)
-                        if (((wave + NT * k) & 3) == q4) z += red[k];
-                    if (i16 == 0) *reinterpret_cast<f32x4*>(crow + 16 * q4 + 4 * g) = z;
-                }
-                for (int e = lane; e < (RES_COLSUM_ROWS / NT - 1) * 3 * 16; e += 64) {
-                    const int rr = e / 48, cc = e - rr * 48;
-                    float* zr = p.colsum + ((size_t)b * RES_COLSUM_ROWS + wave + NT * (rr + 1)) * ld + h * HD + (cc >> 4) * D + (cc & 15) * 4;
-                    *reinterpret_cast<f32x4*>(zr) = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-        }
-        if (!has_next) break;
-#pragma unroll
-        for (int k2 = 0; k2 < KPW; ++k2) *reinterpret_cast<u32x4*>(kimg + (wave + NT * k2) * 1024 + lane * 16) = kst[k2];
-        __syncthreads();                               // the next pair's images, statistics and K image are complete
-        bh = bhn;
-    }
-}
+// (A PERSISTENT form of this kernel -- one workgroup per CU walking its pairs, the next pair's Q / dO tiles loaded into
+// registers one or two query tiles ahead and written over the tiles the current pair is done with, delta / lse2 of the next pair
+// computed on the way, its K image held in registers across the epilogue -- was built and verified in round 3 (git history:
+// attn_bwd_fusedp_kernel).  384 us with one staging set, 411 us with two, against 355 us for this kernel at the time: the staging
+// work (two loads, a dot product and 3 DPP steps per tile on half of the waves, which the barrier of every query tile makes
+// everyone wait for), 60-80 spilled registers at the 256-VGPR limit and the exposed K / V fetch at the pair seam cost more than
+// the overlapped load phase returns.  Touching the next round's lines into L2 / Infinity Cache from this kernel was measured too:
+// 368 vs 360 us, no gain.  Not kept)

@@ -41,25 +41,6 @@ for B, T, H in [(2, 65, 3), (1, 129, 1), (3, 129, 2), (2, 257, 3), (5, 257, 12)]
     ok &= good
     print(f'B={B} T={T} H={H}: err vs fp32 autograd old {e_old:.2e} new {e_new:.2e} | new-old dq {Dq:.2e} dk {Dk:.2e} dv {Dv:.2e} '
           f'last row {last:.2e} | colsum err {cs_err:.1e} | {"ok" if good else "FAIL"}', flush=True)
-for B, T, H in [(30, 257, 12), (70, 129, 8), (150, 65, 8)]:          # more pairs than CUs (x2 / x4 workgroups per CU): the persistent loop
-    D = 64 * H
-    g = torch.Generator().manual_seed(T + B)
-    qkv = (torch.randn(B * T, 3 * D, generator=g) * 1.5).to(torch.bfloat16).cuda()
-    dout = torch.randn(B * T, D, generator=g).to(torch.bfloat16).cuda()
-    out, lse = ops.attention_fwd(qkv, B, T, H)
-    lib.p4p_set_attention_variant(8)
-    old, old_cs = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
-    old, old_cs = old.clone(), old_cs.clone()
-    lib.p4p_set_attention_variant(16)
-    new, new_cs = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
-    ref = ref_grad(qkv, dout, B, T, H)
-    sc = max(ref.abs().max().item(), 1.0)
-    e_old, e_new = (old.float() - ref).abs().max().item() / sc, (new.float() - ref).abs().max().item() / sc
-    cs_err = (new_cs.double() - new.double().sum(0)).abs().max().item() / max(new.float().abs().sum(0).max().item(), 1.0)
-    nd = (new.float() - old.float()).abs().max().item()
-    good = e_new <= 3e-2 and cs_err <= 1e-5 and torch.isfinite(new.float()).all().item() and nd < 0.1
-    ok &= good
-    print(f'persistent B={B} T={T} H={H}: err vs fp32 autograd old {e_old:.2e} new {e_new:.2e} | new-old {nd:.2e} | colsum err {cs_err:.1e} | {"ok" if good else "FAIL"}', flush=True)
 if not ok:
     sys.exit(1)
 
@@ -81,18 +62,11 @@ def timeit(f, n=20):
 
 
 for rnd in range(3):
-    for v, name in ((8, 'two-kernel'), (32, 'fused no shift'), (0, 'fused'), ((1 << 8) + (20 << 10), 'fused 2ph 20k'), ((2 << 8) + (10 << 10), 'fused 3ph 10k'), (16, 'persistent')):
+    for v, name in ((8, 'two-kernel'), (32, 'fused no shift'), (0, 'fused'), ((2 << 8) + (10 << 10), 'fused 3ph 10k'), ((3 << 8) + (8 << 10), 'fused 4ph 8k'), ((3 << 8) + (5 << 10), 'fused 4ph 5k'), ((2 << 8) + (7 << 10), 'fused 3ph 7k')):
         lib.p4p_set_attention_variant(v)
         a = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, B, T, H))
         b = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True))
         print(f'round {rnd} {name:16s}: bwd {a:7.1f} us   with colsum {b:7.1f} us', flush=True)
-lib.p4p_set_attention_variant(0)
-plain = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
-plain = (plain[0].clone(), plain[1].clone())
-lib.p4p_set_attention_variant(16)
-pers = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
-print('persistent == plain fused at B=256:', torch.equal(pers[0], plain[0]), torch.equal(pers[1], plain[1]),
-      'max diff', (pers[0].float() - plain[0].float()).abs().max().item())
 lib.p4p_set_attention_variant(0)
 ref = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
 ref = (ref[0].clone(), ref[1].clone())
