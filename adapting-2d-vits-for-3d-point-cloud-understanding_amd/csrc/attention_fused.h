@@ -508,6 +508,12 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
     FZ_STAMP(6);
 }
 
+// (Two wave groups HALF a query tile apart -- waves w and w + NT / 2 share a SIMD and run every phase of a tile at the same time;
+// group B one half-step (scores + softmax | dV / dK + dQ) behind group A, a barrier after every half -- was built and verified:
+// 307 us against 297 us, the loop 26.8k cycles instead of 23.7k.  The loop is not bound by matrix pipe and VALU taking turns but
+// by the LDS: ~1,470 LDS-array cycles per tile (every wave reads the same Q / dO tile as row fragments AND as transposed
+// fragments: 128 of the 208 KB a tile moves) against 1,280 MFMA cycles per SIMD; a second barrier per tile only adds.  Not kept.)
+//
 // (A PERSISTENT form of this kernel -- one workgroup per CU walking its pairs, the next pair's Q / dO tiles loaded into
 // registers one or two query tiles ahead and written over the tiles the current pair is done with, delta / lse2 of the next pair
 // computed on the way, its K image held in registers across the epilogue -- was built and verified in round 3 (git history:

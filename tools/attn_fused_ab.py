@@ -62,7 +62,7 @@ def timeit(f, n=20):
 
 
 for rnd in range(3):
-    for v, name in ((8, 'two-kernel'), (32, 'fused no shift'), (0, 'fused'), ((2 << 8) + (10 << 10), 'fused 3ph 10k'), ((3 << 8) + (8 << 10), 'fused 4ph 8k'), ((3 << 8) + (5 << 10), 'fused 4ph 5k'), ((2 << 8) + (7 << 10), 'fused 3ph 7k')):
+    for v, name in ((8, 'two-kernel'), (32, 'fused no shift'), (0, 'fused'), ((1 << 8) + (12 << 10), 'fused 2ph 12k'), ((2 << 8) + (7 << 10), 'fused 3ph 7k')):
         lib.p4p_set_attention_variant(v)
         a = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, B, T, H))
         b = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True))
