@@ -4,6 +4,8 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import p4p_amd
 from p4p_amd import ops, _lib
+if os.environ.get('P4P_DEBUG_LIB'):          # A/B of two builds of the library in one gpurun call
+    _lib.LIB_PATH = os.path.abspath(os.environ['P4P_DEBUG_LIB'])
 lib = _lib.lib()
 
 
@@ -62,7 +64,7 @@ def timeit(f, n=20):
 
 
 for rnd in range(3):
-    for v, name in ((8, 'two-kernel'), (32, 'fused no shift'), (0, 'fused'), ((1 << 8) + (12 << 10), 'fused 2ph 12k'), ((2 << 8) + (7 << 10), 'fused 3ph 7k')):
+    for v, name in ((8, 'two-kernel'), (0, 'fused')):
         lib.p4p_set_attention_variant(v)
         a = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, B, T, H))
         b = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True))

@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, 'adapting-2d-vits-for-3d-point-cloud-understanding_amd', 'csrc')
 so = '/tmp/libp4p_fzstamps.so'
 subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '-shared', '--offload-arch=gfx950', '-ffp-contract=off',
-                       '-fno-honor-nans', '-Wno-unused-value', '-Wno-pass-failed', '-DP4P_FZ_STAMPS', '-I', CS,
+                       '-fno-honor-nans', '-fno-slp-vectorize', '-Wno-unused-value', '-Wno-pass-failed', '-DP4P_FZ_STAMPS', '-I', CS,
                        os.path.join(CS, 'attention.hip'), '-x', 'hip', os.path.join(CS, 'capi.cpp'), '-o', so])
 lib = ctypes.CDLL(so)
 B, T, H = 256, 257, 12
