@@ -82,6 +82,9 @@ __device__ __forceinline__ void stage_rows(const __bf16* __restrict__ base, size
     }
 }
 
+// (Running source pointers instead of this clamp / multiply chain were measured in the streaming backward kernels: slower,
+// 1,255 -> 1,338 us at T = 513 -- eight more VGPRs cost more than the ~40 VALU instructions per tile they save; the forward keeps
+// its own running pointers.)
 // b128 fragment: rows r16*16 + i, contraction columns 32ks + 8g .. +7
 __device__ __forceinline__ bf16x8 frag_rows(const char* tile, int r16, int ks, int lane) {
     const int i = lane & 15, g = lane >> 4;
@@ -172,9 +175,12 @@ __device__ __forceinline__ float xor_lanes_sum(float v) { return quad_rows_sum(v
 // ------------------------------------------------------------------------------------------------
 // One K/V tile of the forward pass for a wave's 16 queries.  MASK is a compile-time flag: only the ragged last
 // tile pays for the key masking (as a runtime condition hipcc if-converts it into 16 v_cndmask per tile).
+// `lacc` = row sums of the bf16-ROUNDED numerators (what the P.V product sums), from the matrix pipe: one more MFMA per 32 keys
+// against an all-ones A operand instead of 16 VALU adds per tile (every register of lacc holds the lane's query's sum).
+// The accumulators are rescaled only when some lane's maximum grew (wave-uniform branch; alpha = 1 exactly otherwise).
 template <bool MASK>
 __device__ __forceinline__ void attn_fwd_tile(const char* kt_lds, const char* vt_lds, const bf16x8 (&qf)[2], f32x4 (&o)[4],
-                                              float& m, float& lsum, float c, int key0, int T, int lane) {
+                                              float& m, f32x4& lacc, float c, int key0, int T, int lane) {
     const int g = lane >> 4;
     const int nvalid = MASK ? T - key0 : 64;            // valid keys in this tile (wave-uniform)
     f32x4 s[4];
@@ -198,27 +204,27 @@ __device__ __forceinline__ void attn_fwd_tile(const char* kt_lds, const char* vt
 #pragma unroll
     for (int k16 = 1; k16 < 4; ++k16) mx = fmaxf(mx, fmaxf(fmaxf(s[k16][0], s[k16][1]), fmaxf(s[k16][2], s[k16][3])));
     mx = xor_lanes_max(mx) * c;
-    const float mnew = fmaxf(m, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-    m = mnew;
-    float ps = 0.f;
+    if (__builtin_amdgcn_ballot_w64(mx > m) != 0) {
+        const float mnew = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+        m = mnew;
+        lacc *= alpha;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[d] *= alpha;
+    }
 #pragma unroll
     for (int k16 = 0; k16 < 4; ++k16)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            s[k16][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[k16][r], c, -mnew));
-            ps += s[k16][r];
-        }
-    lsum = lsum * alpha + ps;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) o[d] *= alpha;
+        for (int r = 0; r < 4; ++r) s[k16][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[k16][r], c, -m));
     bf16x8 pb[2] = {pack_pair(s[0], s[1]), pack_pair(s[2], s[3])};
+    const bf16x8 ones = {f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f)};
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
         if (MASK && ss * 32 >= nvalid) continue;          // no valid key in this 32-key contraction step
 #pragma unroll
         for (int d = 0; d < 4; ++d)
             o[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(vt_lds, ss, d, lane), pb[ss], o[d], 0, 0, 0);
+        lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[ss], lacc, 0, 0, 0);
     }
 }
 
@@ -244,7 +250,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
     f32x4 o[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY, lsum = 0.f;
+    float m = -INFINITY;
+    f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
 
     // LDS-DMA sources of this lane's 2 K pieces and 2 V pieces for tile 0; a full tile further = +64 rows.
     // Only the ragged last tile needs row clamping (stage_rows); full tiles just advance the pointers.
@@ -281,14 +288,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
         STAGE_FENCE();
         const char* cur = lds + (kt & 1) * 2 * TILE_BYTES;
         if (kt + 1 < nkt) stage_any(kt + 1, lds + ((kt + 1) & 1) * 2 * TILE_BYTES);
-        if (wave_active) attn_fwd_tile<false>(cur, cur + TILE_BYTES, qf, o, m, lsum, c, kt * 64, T, lane);
+        if (wave_active) attn_fwd_tile<false>(cur, cur + TILE_BYTES, qf, o, m, lacc, c, kt * 64, T, lane);
     }
     if (nfull < nkt) {
         STAGE_FENCE();
         const char* cur = lds + (nfull & 1) * 2 * TILE_BYTES;
-        if (wave_active) attn_fwd_tile<true>(cur, cur + TILE_BYTES, qf, o, m, lsum, c, nfull * 64, T, lane);
+        if (wave_active) attn_fwd_tile<true>(cur, cur + TILE_BYTES, qf, o, m, lacc, c, nfull * 64, T, lane);
     }
-    const float l = xor_lanes_sum(lsum);
+    const float l = lacc[0];
     const float inv = 1.0f / l;
     if (q < T) {
         __bf16* dst = p.out + ((size_t)b * T + q) * D + h * HD;
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
 // as the matrix pipe.  With QT tiles per wave every K / V fragment read feeds QT MFMAs: LDS bytes per FLOP drop by QT.
 template <bool MASK, int QT>
 __device__ __forceinline__ void attn_fwd_tile_q(const char* kt_lds, const char* vt_lds, const bf16x8 (&qf)[QT][2],
-                                                f32x4 (&o)[QT][4], float (&m)[QT], float (&lsum)[QT], float c, int key0, int T,
+                                                f32x4 (&o)[QT][4], float (&m)[QT], f32x4 (&lacc)[QT], float c, int key0, int T,
                                                 int lane) {
     const int g = lane >> 4;
     const int nvalid = MASK ? T - key0 : 64;
@@ -339,23 +346,22 @@ __device__ __forceinline__ void attn_fwd_tile_q(const char* kt_lds, const char* 
         for (int k16 = 1; k16 < 4; ++k16)
             mx = fmaxf(mx, fmaxf(fmaxf(s[t][k16][0], s[t][k16][1]), fmaxf(s[t][k16][2], s[t][k16][3])));
         mx = xor_lanes_max(mx) * c;
-        const float mnew = fmaxf(m[t], mx);
-        const float alpha = __builtin_amdgcn_exp2f(m[t] - mnew);
-        m[t] = mnew;
-        float ps = 0.f;
+        if (__builtin_amdgcn_ballot_w64(mx > m[t]) != 0) {       // some lane's maximum grew: rescale (see attn_fwd_tile)
+            const float mnew = fmaxf(m[t], mx);
+            const float alpha = __builtin_amdgcn_exp2f(m[t] - mnew);
+            m[t] = mnew;
+            lacc[t] *= alpha;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) o[t][d] *= alpha;
+        }
 #pragma unroll
         for (int k16 = 0; k16 < 4; ++k16)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[t][k16][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][k16][r], c, -mnew));
-                ps += s[t][k16][r];
-            }
-        lsum[t] = lsum[t] * alpha + ps;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) o[t][d] *= alpha;
+            for (int r = 0; r < 4; ++r) s[t][k16][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][k16][r], c, -m[t]));
         pb[t][0] = pack_pair(s[t][0], s[t][1]);
         pb[t][1] = pack_pair(s[t][2], s[t][3]);
     }
+    const bf16x8 ones = {f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f), f2bf(1.f)};
 #pragma unroll
     for (int ss = 0; ss < 2; ++ss) {
         if (MASK && ss * 32 >= nvalid) continue;
@@ -365,6 +371,8 @@ __device__ __forceinline__ void attn_fwd_tile_q(const char* kt_lds, const char* 
 #pragma unroll
             for (int t = 0; t < QT; ++t) o[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[t][ss], o[t][d], 0, 0, 0);
         }
+#pragma unroll
+        for (int t = 0; t < QT; ++t) lacc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[t][ss], lacc[t], 0, 0, 0);
     }
 }
 
@@ -389,7 +397,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_q_kernel(AttnParams p
     const int q0 = qb * QT * 64 + wave * QT * 16;            // this wave's QT consecutive 16-query tiles
     bf16x8 qf[QT][2];
     f32x4 o[QT][4];
-    float m[QT], lsum[QT];
+    float m[QT];
+    f32x4 lacc[QT];
 #pragma unroll
     for (int tq = 0; tq < QT; ++tq) {
         int q = q0 + tq * 16 + i;
@@ -400,7 +409,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_q_kernel(AttnParams p
 #pragma unroll
         for (int d = 0; d < 4; ++d) o[tq][d] = f32x4{0.f, 0.f, 0.f, 0.f};
         m[tq] = -INFINITY;
-        lsum[tq] = 0.f;
+        lacc[tq] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int rin = lane >> 3, chunk = (lane & 7) ^ rin;
     const __bf16* ksrc[2];
@@ -412,12 +421,14 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_q_kernel(AttnParams p
         vsrc[qq] = vbase + off;
     }
     const size_t tile_step = (size_t)64 * ld;
-    auto stage_any = [&](int kt, char* buf) {
+    auto stage_any = [&](int kt, char* buf) {          // tiles are staged in ascending order: the sources advance by one tile per call
         if ((kt + 1) * 64 <= T) {
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
-                __builtin_amdgcn_global_load_lds(GLB_PTR(ksrc[qq] + kt * tile_step), LDS_PTR(buf + (wave * 2 + qq) * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds(GLB_PTR(vsrc[qq] + kt * tile_step), LDS_PTR(buf + TILE_BYTES + (wave * 2 + qq) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_PTR(ksrc[qq]), LDS_PTR(buf + (wave * 2 + qq) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLB_PTR(vsrc[qq]), LDS_PTR(buf + TILE_BYTES + (wave * 2 + qq) * 1024), 16, 0, 0);
+                ksrc[qq] += tile_step;
+                vsrc[qq] += tile_step;
             }
         } else {
             stage_rows(kbase, ld, kt * 64, T, buf, wave, lane);
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_q_kernel(AttnParams p
 #endif
         const char* cur = lds + (kt & 1) * 2 * TILE_BYTES;
         if (kt + 1 < nkt) stage_any(kt + 1, lds + ((kt + 1) & 1) * 2 * TILE_BYTES);
-        if (wave_active) attn_fwd_tile_q<false, QT>(cur, cur + TILE_BYTES, qf, o, m, lsum, c, kt * 64, T, lane);
+        if (wave_active) attn_fwd_tile_q<false, QT>(cur, cur + TILE_BYTES, qf, o, m, lacc, c, kt * 64, T, lane);
 #ifdef P4P_LONE_STAMPS
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long tc = __builtin_readcyclecounter();
@@ -462,11 +473,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_q_kernel(AttnParams p
     if (nfull < nkt) {
         STAGE_FENCE();
         const char* cur = lds + (nfull & 1) * 2 * TILE_BYTES;
-        if (wave_active) attn_fwd_tile_q<true, QT>(cur, cur + TILE_BYTES, qf, o, m, lsum, c, nfull * 64, T, lane);
+        if (wave_active) attn_fwd_tile_q<true, QT>(cur, cur + TILE_BYTES, qf, o, m, lacc, c, nfull * 64, T, lane);
     }
 #pragma unroll
     for (int tq = 0; tq < QT; ++tq) {
-        const float l = xor_lanes_sum(lsum[tq]);
+        const float l = lacc[tq][0];
         const float inv = 1.0f / l;
         const int q = q0 + tq * 16 + i;
         if (q < T) {
@@ -536,12 +547,13 @@ __global__ __launch_bounds__(RES_NW * 64, 4) void attn_fwd_res_kernel(AttnParams
         f32x4 o[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float m = -INFINITY, lsum = 0.f;
+        float m = -INFINITY;
+        f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
         for (int kt = 0; kt < nfull; ++kt)
-            attn_fwd_tile<false>(klds + kt * TILE_BYTES, vlds + kt * TILE_BYTES, qf[s], o, m, lsum, c, kt * 64, T, lane);
+            attn_fwd_tile<false>(klds + kt * TILE_BYTES, vlds + kt * TILE_BYTES, qf[s], o, m, lacc, c, kt * 64, T, lane);
         if (nfull < nkt)
-            attn_fwd_tile<true>(klds + nfull * TILE_BYTES, vlds + nfull * TILE_BYTES, qf[s], o, m, lsum, c, nfull * 64, T, lane);
-        const float l = xor_lanes_sum(lsum);
+            attn_fwd_tile<true>(klds + nfull * TILE_BYTES, vlds + nfull * TILE_BYTES, qf[s], o, m, lacc, c, nfull * 64, T, lane);
+        const float l = lacc[0];
         const float inv = 1.0f / l;
         const int q = qt * 16 + i;
         if (q < T) {

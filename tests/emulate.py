@@ -177,7 +177,8 @@ def _attention_two_pass(s, v, c):
 
 def _online_chain(s, v, c, key_groups, m=None, lsum=None, o=None):
     """One online-softmax chain over the given key groups (lists of key indices), attention.hip: attn_fwd_tile: running
-    maximum, numerators rounded to bf16 for P.V but summed in fp32, accumulator rescaled per group.  A group of ONE key
+    maximum, numerators rounded to bf16 for P.V AND for the denominator (round 3: the row sums come out of the matrix pipe, one MFMA
+    against an all-ones operand, as in attention_lone.h), accumulator rescaled per group.  A group of ONE key
     whose numerator is exactly 1 reproduces the 'last key first' start of attention_lone.h."""
     B, H, R, _ = s.shape
     if m is None:
@@ -189,7 +190,7 @@ def _online_chain(s, v, c, key_groups, m=None, lsum=None, o=None):
         mnew = torch.maximum(m, (st.max(-1, keepdim=True).values * c).detach())
         alpha = torch.exp2(m - mnew)
         p = _exp2_fma(st, c, mnew)
-        lsum = lsum * alpha + p.sum(-1, keepdim=True)
+        lsum = lsum * alpha + _r(p).sum(-1, keepdim=True)
         o = o * alpha + _r(p) @ v[:, :, keys]
         m = mnew
     return m, lsum, o
@@ -199,8 +200,8 @@ def attention_emulated(qkv, B, T, H, round_output=True):
     """qkv [B*T, 3*H*64] (bf16-valued fp32) -> attention output [B*T, H*64].  Two contracts, chosen as the library
     chooses its kernel (attention_lone_mode):
     'online'  (csrc/attention.hip: attn_fwd_tile): online softmax over 64-key tiles in ascending order: running maximum m
-              in the base-2 domain c*s, numerators p = exp2(c*s - m) ROUNDED TO bf16 for the P.V product but summed in fp32
-              for the denominator, accumulator rescaled by exp2(m_old - m_new) per tile, one division at the end;
+              in the base-2 domain c*s, numerators p = exp2(c*s - m) ROUNDED TO bf16 for the P.V product and for the denominator
+              alike, accumulator rescaled by exp2(m_old - m_new) per tile, one division at the end;
     'two_pass' (csrc/attention_lone.h): see _attention_two_pass.
     The result is rounded to bf16 (round_output=False: the fp32 value in front of that rounding)."""
     hd = 64
