@@ -170,7 +170,7 @@ def _pmc_traffic(kernel_tag):
     return None, None
 
 
-def instrumented_roofline(stepper, batch, steps, measure=True):
+def instrumented_roofline(stepper, batch, steps, measure=True, attn_dims=None):
     """Rooflines measured live: the library brackets exactly the launches of one kind with HIP events on the launch
     stream (include/p4p_hip.h: p4p_prof_enable / p4p_prof_collect) during `steps` extra training steps per kind;
     algorithmic FLOPs = 2 M N K per GEMM launch, 4 B H T^2 64 per attention forward (x 2.5 backward).  The headline entry
@@ -207,12 +207,32 @@ def instrumented_roofline(stepper, batch, steps, measure=True):
         'flop_per_launch': dom['flops'] / dom['launches'], 'ms_per_step': dom['ms'] / steps,
         'all_mfma_gemms': {'achieved': agg_fl / (agg_ms * 1e-3) * 1e-12,
                            'frac': agg_fl / (agg_ms * 1e-3) * 1e-12 / PEAK_BF16_TFLOPS, 'ms_per_step': agg_ms / steps},
-        'attention': {'fwd_TFLOPs': tf(res[3]), 'bwd_TFLOPs': tf(res[4]),
-                      'fwd_frac': (tf(res[3]) or 0) / PEAK_BF16_TFLOPS, 'bwd_frac': (tf(res[4]) or 0) / PEAK_BF16_TFLOPS,
-                      'ms_per_step': (res[3]['ms'] + res[4]['ms']) / steps},
+        'attention': _attention_roofline(res[3], res[4], steps, attn_dims, tf),
         'per_kernel': {r['name']: {'TFLOP/s': tf(r), 'ms_per_step': r['ms'] / steps,
                                    'launches_per_step': r['launches'] / steps} for r in res.values()},
     }
+
+
+def _attention_roofline(fwd, bwd, steps, dims, tf):
+    """Attention against BOTH roofs.  At head_dim 64 the algorithmic intensity is 4 T^2 64 / (4 T 128 B) = T / 2 FLOP per byte
+    forward (q, k, v read, o written once): 128 at T = 257, 256 at T = 513, 1,024 at T = 2049, against a machine balance of
+    2,500 / 8 = 312 -- so the model's own N = 1024 shape is HBM bound (and the MFMA fraction says little there), N = 2048 sits on
+    the ridge, N = 8192 is matrix-pipe bound.  Algorithmic bytes per launch: forward 4 x B T D x 2 B; backward 8 x B T D x 2 B
+    (q, k, v, dO, O read; dq, dk, dv written), each tensor counted once."""
+    out = {'fwd_TFLOPs': tf(fwd), 'bwd_TFLOPs': tf(bwd),
+           'fwd_frac': (tf(fwd) or 0) / PEAK_BF16_TFLOPS, 'bwd_frac': (tf(bwd) or 0) / PEAK_BF16_TFLOPS,
+           'ms_per_step': (fwd['ms'] + bwd['ms']) / steps}
+    if dims and fwd['ms'] > 0 and bwd['ms'] > 0:
+        B, T, D = dims
+        tensor = B * T * D * 2.0
+        fb, bb = 4 * tensor * fwd['launches'], 8 * tensor * bwd['launches']
+        out.update({'shape': {'B': B, 'T': T, 'D': D, 'head_dim': 64},
+                    'flop_per_byte_fwd': T / 2.0, 'machine_balance': PEAK_BF16_TFLOPS / 8.0,
+                    'bound': 'hbm' if T / 2.0 < PEAK_BF16_TFLOPS / 8.0 else 'mfma',
+                    'fwd_hbm_TBps': fb / (fwd['ms'] * 1e-3) * 1e-12, 'bwd_hbm_TBps': bb / (bwd['ms'] * 1e-3) * 1e-12,
+                    'fwd_hbm_frac': fb / (fwd['ms'] * 1e-3) / 8e12, 'bwd_hbm_frac': bb / (bwd['ms'] * 1e-3) / 8e12,
+                    'fwd_us_per_launch': fwd['ms'] / fwd['launches'] * 1e3, 'bwd_us_per_launch': bwd['ms'] / bwd['launches'] * 1e3})
+    return out
 
 
 def index_ops_roofline(B, N, S, k, device, iters=20):
@@ -468,7 +488,8 @@ def main():
     roof = None
     if not args.no_roofline:
         # all ranks run the instrumented steps (a step holds collectives); only rank 0 brackets its kernels with events
-        roof = instrumented_roofline(stepper, batch, max(2, min(args.steps, 3)), measure=rank == 0)
+        roof = instrumented_roofline(stepper, batch, max(2, min(args.steps, 3)), measure=rank == 0,
+                                     attn_dims=(args.batch, 196 if apf else args.points // 4 + 1, vd))
     if rank == 0 and roof is not None:
         if apf:
             roof['index_ops'] = index_ops_roofline(args.batch, args.points, 196, 32, device)
@@ -487,7 +508,7 @@ def main():
         ns_steps = 10
         ns_el, _, _ = timed_steps(stepper, ns_batch, ns_steps, fence, False, device)
         ns_fb, _, _ = timed_steps(stepper, ns_batch, 5, fence, False, device, optim=False)
-        ns_roof = instrumented_roofline(stepper, ns_batch, 2) if not args.no_roofline else None
+        ns_roof = instrumented_roofline(stepper, ns_batch, 2, attn_dims=(nb, npts // 4 + 1, vd)) if not args.no_roofline else None
         fl = flop_per_cloud(npts, vd, vl)
         v = nb * ns_steps / ns_el
         ns = {'workload': f'Pix4Point {args.vit} N={npts} k=16, batch {nb}, 1 GPU (same step as the headline line)',
@@ -502,6 +523,31 @@ def main():
             ns['index_ops'] = index_ops_roofline(nb, npts, npts // 4, 16, device)
         log('north-star point (N=2048, B=256) done')
         del ns_batch
+    # ---- the third size north_star names: N=8192 (BASELINE configs[4]: ViT-L/24 tokens, 8 clouds per GPU), one GPU, short
+    n8k = None
+    if default_config and world == 1 and not args.no_north_star:
+        import copy
+        del stepper
+        torch.cuda.empty_cache()
+        a2 = copy.copy(args)
+        a2.vit, a2.points, a2.batch = 'vit_large_patch16_384', 8192, 8
+        ld_, ll_, lh_, _, _ = parse_model_name(a2.vit)
+        a2.dim = ld_
+        st2 = Stepper(a2, device, False)
+        b2 = synthetic_batch(a2.batch, a2.points, a2.classes, 777, device)
+        for _ in range(2):
+            st2.step(*b2)
+        k_steps = 5
+        el2, _, _ = timed_steps(st2, b2, k_steps, fence, False, device)
+        fl2 = flop_per_cloud(a2.points, ld_, ll_)
+        v2 = a2.batch * k_steps / el2
+        n8k = {'workload': f'Pix4Point {a2.vit} (D={ld_}, {ll_} blocks, {lh_} heads) N=8192 k=16, batch {a2.batch}, 1 GPU (same step as the headline line)',
+               'clouds_per_sec': v2, 'ms_per_step': el2 / k_steps * 1e3, 'steps': k_steps,
+               'algorithmic_gflop_per_cloud': fl2 * 1e-9, 'algorithmic_tflops': v2 * fl2 * 1e-12,
+               'mfma_frac_whole_step': v2 * fl2 * 1e-12 / PEAK_BF16_TFLOPS}
+        log('N=8192 ViT-L/24 point done')
+        del st2, b2
+        torch.cuda.empty_cache()
     if distributed:
         dist.barrier()
     cpu = None
@@ -543,6 +589,8 @@ def main():
             out['roofline'] = roof
         if ns:
             out['north_star_point'] = ns
+        if n8k:
+            out['n8192_point'] = n8k
         if cpu:
             out['cpu_baseline'] = cpu
         print(json.dumps(out))
