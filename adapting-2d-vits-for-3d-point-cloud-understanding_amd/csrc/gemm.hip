@@ -35,7 +35,7 @@ __device__ float g_zero_page[64];   // 256 B of zeros: LDS-DMA source for rows p
 // tile configuration: 0 = auto, 1 = 128x128 (4 waves), 2 = 256x128 (8 waves), 3 = 256x256 (8 waves),
 // 4 = 256x128 / 4 waves / K-step 32 / 3-stage ring (gemm_tn3.h); 11-13 = 1-3 with pinned scheduling
 static int g_gemm_variant = 0;
-static int g_tn4_persistent = 1;            // A/B switch: 0 = one workgroup per tile (gemm_tn4.h) everywhere
+static int g_tn4_persistent = 1;            // A/B switch: 0 = one workgroup per tile (gemm_tn4.h) everywhere; bit 1: no banded tile order
 extern "C" int p4p_set_gemm_persistent(int v) { int o = g_tn4_persistent; g_tn4_persistent = v; return o; }
 extern "C" int p4p_set_gemm_variant(int v) { int o = g_gemm_variant; g_gemm_variant = v; return o; }
 
@@ -202,8 +202,10 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
                 int tiles = ceil_div(p.M, 256) * (p.N / 256);
                 // several tiles per CU and an even number (>= 4) of K-tiles: the persistent loop of gemm_tn4p.h hides the per-tile
                 // dispatch + pipeline-fill latency behind the previous tile's epilogue
-                if (g_tn4_persistent && tiles >= 512 && p.K % 128 == 0 && p.K >= 256 && p.K <= 2304) {
-                    hipLaunchKernelGGL((gemm_tn4p_kernel<EPI>), dim3(256), dim3(512), 0, st, p);
+                if ((g_tn4_persistent & 1) && tiles >= 512 && p.K % 128 == 0 && p.K >= 256 && p.K <= 2304) {
+                    GemmParams pb = p;
+                    pb.band = (g_tn4_persistent & 2) ? 0 : 1;
+                    hipLaunchKernelGGL((gemm_tn4p_kernel<EPI>), dim3(256), dim3(512), 0, st, pb);
                     P4P_LAUNCH_CHECK();
                     return 0;
                 }
@@ -253,7 +255,7 @@ extern "C" int p4p_gemm_tn_bf16(int epi, const void* A, const void* W, void* out
     P4P_CHECK(N % 8 == 0, "p4p_gemm_tn_bf16: N=%d must be a multiple of 8", N);
     GemmParams p;
     p.A = (const __bf16*)A; p.W = (const __bf16*)W; p.out = out; p.bias = bias; p.resid = resid;
-    p.pre = (__bf16*)pre; p.rowgrp = rowgrp; p.stats = stats; p.M = M; p.N = N; p.K = K; p.group = group; p.ldk = K;
+    p.pre = (__bf16*)pre; p.rowgrp = rowgrp; p.stats = stats; p.M = M; p.N = N; p.K = K; p.group = group; p.ldk = K; p.band = 0;
     hipStream_t st = (hipStream_t)stream;
     struct ProfScope {      // gemm_tn: brackets the (one or two, when the tail is peeled) launches of this call
         hipStream_t s; bool on;

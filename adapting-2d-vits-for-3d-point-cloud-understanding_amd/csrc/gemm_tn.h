@@ -27,6 +27,7 @@ struct GemmParams {
     float* stats;          // [tiles_m][2][N] f32 partial column sums / sums of squares
     int M, N, K, group;
     int ldk;               // row stride of A and W in elements (= K, except for the split-K launches of gemm_tn2_kernel)
+    int band;              // gemm_tn4p_kernel: banded tile order for wide outputs (band_remap); 0 = plain XCD-contiguous order
 };
 
 enum {
@@ -63,6 +64,20 @@ __device__ __forceinline__ void gelu_and_dgelu(float x, float& y, float& dy) {
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+// Wide outputs (tiles_n a multiple of 4, >= 8: the N = 3072 GEMMs fc1 / dfc2, 12 tiles per row panel): in the order above the 32
+// workgroups of an XCD cover 2.7 row panels x ALL column tiles at any time, so every time step streams the whole weight matrix
+// (12 panels x 393 KB = 4.7 MB at K = 768: it does not stay in the 4-MB L2) -- FETCH_SIZE 623 MB per fc1 launch for 106 MB of
+// operands.  Inside every band of 8 row panels the tiles are therefore taken column group by column group (8 row panels x 4
+// column tiles = 32 workgroups = one time step): a step shares 8 A panels + 4 W panels, consecutive steps of a band keep the A
+// panels.  `t` is the XCD-contiguous index of xcd_remap; bands must tile the XCD's run (checked by the caller's `banded`).
+// Measured (tools/band_ab.py, bit-identical outputs): fc1 377 -> 368 us, 723 -> 709 us at M = 131k; dfc2 unchanged -- the fabric
+// traffic it removes was not what these GEMMs wait for; the column group outermost over the XCD's whole run measured the same.
+__device__ __forceinline__ int band_remap(int t, int tiles_n) {
+    const int band = 8 * tiles_n, r = t % band;
+    const int ng = r >> 5, r2 = r & 31;
+    return t - r + (r2 >> 2) * tiles_n + ng * 4 + (r2 & 3);
 }
 
 template <int BM_, int BN_, int WAVES_M, int WAVES_N, int EPI, bool PIN, int ABL = 0>   // ABL: timing-only ablations (bit0: no LDS-DMA in the loop, bit1: no fragment reads); bit2: interleaved issue order

@@ -112,12 +112,14 @@ __global__ __launch_bounds__(512) void gemm_tn4p_kernel(GemmParams p) {
         c_slot = slot_of(c_slot, 4);                                                        \
     }
 
+    // every XCD's run of tiles is whole bands of 8 row panels (gemm_tn.h: band_remap)
+    const bool banded = p.band && tiles_n % 4 == 0 && tiles_n >= 8 && ntiles % 8 == 0 && (ntiles / 8) % (8 * tiles_n) == 0;
     bool fresh = true;                                     // the tile's first 7 half-tiles are not in flight yet
     for (int it = blockIdx.x; it < ntiles; it += gridDim.x) {
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
         rin = lane >> 3; chunk = (lane & 7) ^ rin; li = lane & 15; g = lane >> 4;
         fo0 = li * 128 + ((g ^ (li & 7)) << 4); fo1 = fo0 ^ 64;
-        const int tile = xcd_remap(it, ntiles);
+        const int tile = banded ? band_remap(xcd_remap(it, ntiles), tiles_n) : xcd_remap(it, ntiles);
         const int tm = tile / tiles_n;
         const int m0 = tm * 256, n0 = (tile - tm * tiles_n) * 256;
         // the seam: the next tile's source offsets are this tile's plus a wave-uniform byte delta, unless one of the two tiles is
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(512) void gemm_tn4p_kernel(GemmParams p) {
         bool seam = false;
         long long dA = 0, dW = 0;
         if (it + (int)gridDim.x < ntiles) {
-            const int tl = xcd_remap(it + gridDim.x, ntiles), tmn = tl / tiles_n;
+            const int tl = banded ? band_remap(xcd_remap(it + gridDim.x, ntiles), tiles_n) : xcd_remap(it + gridDim.x, ntiles), tmn = tl / tiles_n;
             const int m0n = tmn * 256, n0n = (tl - tmn * tiles_n) * 256;
             seam = m0 + 256 <= p.M && m0n + 256 <= p.M;
             if (seam) {

@@ -176,7 +176,7 @@ int p4p_device_cu_count(void);
 /* experiment switches (tools/gemm_bench.py): tile configuration overrides, 0 = automatic */
 int p4p_set_gemm_variant(int v);
 int p4p_set_wgrad_wide(int v);
-int p4p_set_gemm_persistent(int v);        /* 1 (default): short-K GEMMs with several tiles per CU run the persistent tile loop (gemm_tn4p.h); 0: one workgroup per tile */
+int p4p_set_gemm_persistent(int v);        /* 1 (default): short-K GEMMs with several tiles per CU run the persistent tile loop (gemm_tn4p.h); 0: one workgroup per tile; 3: persistent without the banded tile order of wide outputs */
 int p4p_set_attention_variant(int v);      /* bit 0: no resident forward / dQ, bit 1: no resident dK/dV, bit 2: no two-pass forward */
 
 /* ---- global feature of PointViT.forward_cls_feat (src/models/pix4point.py:260-271) ----
