@@ -1199,7 +1199,7 @@ __global__ __launch_bounds__(RES_DKDV_NW * 64, 2) void attn_bwd_dkdv_res_kernel(
 #include "attention_fused.h"
 
 // experiment switch for tools/attn_ab.py (in-process A/B, default 0 = automatic): bit 0 = no resident forward / dQ,
-// bit 1 = no resident dK/dV, bit 2 = no two-pass (64 n + 1) forward, bit 3 = no fused backward, bit 5 = no start shift of the fused backward.  Nothing in the product path sets it.
+// bit 1 = no resident dK/dV, bit 2 = no two-pass (64 n + 1) forward, bit 3 = no fused backward, bit 5 = no start shift of the fused backward, bit 6 = no key-stationary dK/dV at T = 513.  Nothing in the product path sets it.
 static int g_attn_variant = 0;
 extern "C" int p4p_set_attention_variant(int v) { int o = g_attn_variant; g_attn_variant = v; return o; }
 
@@ -1313,6 +1313,20 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
     P4P_LAUNCH_CHECK();
     if (res && res_dkdv) {
         hipLaunchKernelGGL(attn_bwd_dkdv_res_kernel, dim3(B * H), dim3(RES_DKDV_NW * 64), 0, st, p);
+        P4P_LAUNCH_CHECK();
+        return 0;
+    }
+    if (T == 513 && !(g_attn_variant & 64)) {            // key-stationary dK / dV with Q, dO resident (attention_fused.h); bit 6: off
+        static int ncu = 0;
+        if (!ncu) {
+            int dev = 0;
+            P4P_HIP(hipGetDevice(&dev));
+            P4P_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        }
+        p.stagger_n = ncu; p.stagger_phases = 3; p.stagger_cycles = 12 * 1024;
+        if (g_attn_variant & 32) p.stagger_phases = 1;
+        if (g_attn_variant >> 8) { p.stagger_phases = ((g_attn_variant >> 8) & 3) + 1; p.stagger_cycles = (g_attn_variant >> 10) * 1024; }
+        hipLaunchKernelGGL(attn_bwd_dkdv_ks_kernel<16>, dim3(B * H * 2), dim3(512), 0, st, p);
         P4P_LAUNCH_CHECK();
         return 0;
     }

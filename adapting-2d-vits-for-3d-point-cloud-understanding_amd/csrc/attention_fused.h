@@ -522,3 +522,263 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
 // everyone wait for), 60-80 spilled registers at the 256-VGPR limit and the exposed K / V fetch at the pair seam cost more than
 // the overlapped load phase returns.  Touching the next round's lines into L2 / Infinity Cache from this kernel was measured too:
 // 368 vs 360 us, no gain.  Not kept)
+
+// ================================================================================================================================
+// dK / dV for T = 32 NT + 1 with 8 < NT <= 16 (T = 513: N = 2048 points, the point north_star states its targets at), key-stationary
+// like the kernel above but WITHOUT the dQ part (16 key tiles would need 16 waves of 220 registers, or a dQ hand-off between two
+// workgroups; dQ stays with attn_bwd_dq_q_kernel, which also leaves delta).  One workgroup = 8 waves = one HALF of the keys of a
+// (batch, head) pair: wave w owns keys 256 kh + 32 w ..; Q and dO of the whole sequence resident in LDS (139 KB at T = 513), and a
+// loop over the NT + 1 query tiles with NO barrier and NO LDS write: after the prologue the waves run free.  Against
+// attn_bwd_dkdv_kernel (16 keys per wave, 64-row tiles streamed behind a barrier each): every Q / dO fragment read from LDS feeds
+// a 32x32x16 MFMA (twice the MACs per LDS byte), one load phase per 17 tiles.  The odd key (row L) belongs to key half 0, handled
+// as above (a phase of its own before the loop; the pair (L, L) by VALU on wave 0).
+template <int NT>
+struct KsLds {
+    static constexpr int L = 32 * NT, ROWS = L + 32, IMG = ROWS * 128;
+    static constexpr int OFF_Q = 0, OFF_DO = IMG;
+    static constexpr int OFF_NLSE = 2 * IMG, OFF_NDEL = OFF_NLSE + ROWS * 4;
+    static constexpr int OFF_PART = OFF_NDEL + ROWS * 4;            // [8 + 1][2][64] partial dK / dV rows of the odd key
+    static constexpr int OFF_LONE = OFF_PART + 9 * 2 * 64 * 4;
+    static constexpr int TOTAL = OFF_LONE + 2 * 64 * 4;
+    static_assert(TOTAL <= 160 * 1024, "LDS");
+    static_assert(2 * IMG >= 8 * 32 * FZ_SLAB_STRIDE, "epilogue slabs must fit the Q / dO images");
+};
+
+template <int NT>
+__global__ __launch_bounds__(512, 1) void attn_bwd_dkdv_ks_kernel(AttnParams p) {
+    using LY = KsLds<NT>;
+    constexpr int L = LY::L, ROWS = LY::ROWS, NW = 8, KH = NT / 8;
+    static_assert(NT % 8 == 0, "whole key halves of 8 waves");
+    __shared__ __attribute__((aligned(1024))) char lds[LY::TOTAL];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int kh = blockIdx.x % KH, bh = blockIdx.x / KH, b = bh / p.H, h = bh - b * p.H;
+    const int T = p.T, D = p.D;                       // T = L + 1
+    const size_t ld = (size_t)3 * D;
+    const __bf16* seq = p.qkv + (size_t)b * T * ld;
+    const __bf16* dob = p.dout + (size_t)b * T * D + h * HD;
+    const float c = p.scale * 1.4426950408889634f;
+    char* qs = lds + LY::OFF_Q;
+    char* dos = lds + LY::OFF_DO;
+    float* nlse = reinterpret_cast<float*>(lds + LY::OFF_NLSE);
+    float* ndel = reinterpret_cast<float*>(lds + LY::OFF_NDEL);
+    float* part = reinterpret_cast<float*>(lds + LY::OFF_PART);
+    float* lonekv = reinterpret_cast<float*>(lds + LY::OFF_LONE);
+    const int kk = lane & 31, hh = lane >> 5, i16 = lane & 15, g = lane >> 4;
+    if (p.stagger_phases > 1 && (int)blockIdx.x < p.stagger_n) {       // first round in shifted groups (see attn_bwd_fused_kernel)
+        const int ph = blockIdx.x % p.stagger_phases;
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < (unsigned long long)ph * p.stagger_cycles) __builtin_amdgcn_s_sleep(16);
+    }
+
+    // ---- stage Q, dO (1-KiB pieces of 8 rows; rows L + 1 .. L + 7 repeat row L, the rest of the last tile is zero)
+    {
+        const int rin = lane >> 3;
+        constexpr int NPC = L / 8 + 1;
+        for (int pc = wave; pc < 2 * NPC; pc += NW) {
+            const int isd = pc >= NPC, piece = isd ? pc - NPC : pc;
+            const int row = piece * 8 + rin;
+            const int r = row < T ? row : T - 1;
+            const int chunk = (lane & 7) ^ fz_sig(row);
+            const __bf16* src = isd ? dob + (size_t)r * D + chunk * 8 : seq + (size_t)r * ld + h * HD + chunk * 8;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR((isd ? dos : qs) + piece * 1024), 16, 0, 0);
+        }
+        for (int e = t; e < 2 * 24 * 8; e += NW * 64) {
+            char* img = e >= 24 * 8 ? dos : qs;
+            const int ee = e >= 24 * 8 ? e - 24 * 8 : e;
+            *reinterpret_cast<f32x4*>(img + (L + 8) * 128 + ee * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // ---- this wave's keys: K / V fragments (B operands of S and dP)
+    bf16x8 kf[4], vf[4];
+    {
+        const __bf16* krow = seq + (size_t)(256 * kh + 32 * wave + kk) * ld + D + h * HD + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[s] = *reinterpret_cast<const bf16x8*>(krow + 16 * s);
+            vf[s] = *reinterpret_cast<const bf16x8*>(krow + D + 16 * s);
+        }
+    }
+    // ---- row statistics: -lse2 and -delta (left by the dQ kernel); padding rows of the last tile: lse2 = +inf, P = 0
+    {
+        const float* lse_b = p.lse2 + (size_t)bh * T;
+        const float* del_b = p.delta + (size_t)bh * T;
+        for (int e = t; e < ROWS; e += NW * 64) {
+            nlse[e] = e < T ? -lse_b[e] : -INFINITY;
+            ndel[e] = e < T ? -del_b[e] : 0.f;
+        }
+    }
+    // ---- the odd row against itself (key half 0, wave 0): its share of dK[L], dV[L]
+    if (kh == 0 && wave == 0) {
+        const size_t rl = (size_t)L * ld + h * HD + lane;
+        const float ql = bf2f(seq[rl]), kl = bf2f(seq[rl + D]), vl = bf2f(seq[rl + 2 * D]);
+        const float dol = bf2f(dob[(size_t)L * D + lane]);
+        const float lse_l = p.lse2[(size_t)bh * T + L], dl = p.delta[(size_t)bh * T + L];
+        const float sl = wave_sum_f32(ql * kl);
+        const float dpl = wave_sum_f32(dol * vl) - dl;
+        const float pl = __builtin_amdgcn_exp2f(__builtin_fmaf(sl, c, -lse_l));
+        part[(NW * 2 + 0) * 64 + lane] = bf2f(f2bf(pl * dpl)) * ql;
+        part[(NW * 2 + 1) * 64 + lane] = bf2f(f2bf(pl)) * dol;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __syncthreads();
+
+    // ---- lane-constant LDS bases (attn_bwd_fused_kernel)
+    const char* rowb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rowb[ks] = qs + kk * 128 + (((2 * ks + hh) ^ fz_sig(kk)) << 4);
+    const char* trb[2];
+    {
+        const int rlo = 4 * hh + (i16 >> 2), pq = i16 & 3;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) trb[e] = qs + rlo * 128 + ((((2 * (g & 1) + (pq >> 1)) ^ fz_sig(rlo)) ^ (4 * e)) << 4) + (pq & 1) * 8;
+    }
+    auto tr32 = [&](int img_off, int row0, int sp, int dh) -> bf16x8 {
+        const char* a0 = trb[dh ^ sp] + img_off + row0 * 128 + sp * 2048;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 1024));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, r);
+    };
+    const float* rcb = nlse + 4 * hh;
+    auto rowconst = [&](int arr_off, int row0) -> f32x16 {
+        f32x16 v;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(rcb + arr_off + row0 + 8 * jj);
+            v[4 * jj + 0] = q[0]; v[4 * jj + 1] = q[1]; v[4 * jj + 2] = q[2]; v[4 * jj + 3] = q[3];
+        }
+        return v;
+    };
+    // one query tile against 32 keys: P and dS (bf16, the B operands of the products that sum over the queries)
+    auto front = [&](int row0, const bf16x8 (&kfr)[4], const bf16x8 (&vfr)[4], bf16x8 (&pb)[2], bf16x8 (&db)[2]) {
+        f32x16 s, dp = rowconst(ROWS, row0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(rowb[ks] + row0 * 128), kfr[ks], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(rowb[ks] + LY::IMG + row0 * 128), vfr[ks], dp, 0, 0, 0);
+        }
+        const f32x16 nl = rowconst(0, row0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, nl[r]));
+            dp[r] = s[r] * dp[r];
+        }
+        fz_pack(s, pb);
+        fz_pack(dp, db);
+    };
+    auto back = [&](int row0, const bf16x8 (&pb)[2], const bf16x8 (&db)[2], f32x16 (&dka)[2], f32x16 (&dva)[2]) {
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                dva[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr32(LY::IMG, row0, sp, dh), pb[sp], dva[dh], 0, 0, 0);
+                dka[dh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr32(0, row0, sp, dh), db[sp], dka[dh], 0, 0, 0);
+            }
+    };
+
+    // ---- the odd key (key half 0): wave w takes query tiles w, w + 8, .. against it (column 0 of the B operands)
+    if (kh == 0) {
+        bf16x8 klf[4], vlf[4];
+        const __bf16* krow = seq + (size_t)L * ld + D + h * HD + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 z = {};
+            klf[s] = kk == 0 ? *reinterpret_cast<const bf16x8*>(krow + 16 * s) : z;
+            vlf[s] = kk == 0 ? *reinterpret_cast<const bf16x8*>(krow + D + 16 * s) : z;
+        }
+        f32x16 dkl[2], dvl[2];
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dkl[dh][r] = dvl[dh][r] = 0.f;
+#pragma unroll
+        for (int e = 0; e < NT / NW; ++e) {
+            bf16x8 pb[2], db[2];
+            front(32 * (wave + NW * e), klf, vlf, pb, db);
+            back(32 * (wave + NW * e), pb, db, dkl, dvl);
+        }
+        if (kk == 0) {
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int d = 32 * dh + 8 * jj + 4 * hh;
+                    *reinterpret_cast<f32x4*>(part + (wave * 2 + 0) * 64 + d) = f32x4{dkl[dh][4 * jj], dkl[dh][4 * jj + 1], dkl[dh][4 * jj + 2], dkl[dh][4 * jj + 3]};
+                    *reinterpret_cast<f32x4*>(part + (wave * 2 + 1) * 64 + d) = f32x4{dvl[dh][4 * jj], dvl[dh][4 * jj + 1], dvl[dh][4 * jj + 2], dvl[dh][4 * jj + 3]};
+                }
+        }
+        __syncthreads();                               // (block-uniform branch)
+        if (t < 128) {
+            const int which = t >> 6, d = t & 63;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w <= NW; ++w) v += part[(w * 2 + which) * 64 + d];
+            if (which == 0) v *= p.scale;
+            const __bf16 r = f2bf(v);
+            p.out[((size_t)b * T + L) * ld + (1 + which) * D + h * HD + d] = r;
+            lonekv[which * 64 + d] = bf2f(r);
+        }
+    }
+
+    // ---- the query tiles: no barrier, no LDS write
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk[dh][r] = dv[dh][r] = 0.f;
+#pragma unroll
+    for (int qt = 0; qt <= NT; ++qt) {
+        bf16x8 pb[2], db[2];
+        front(32 * qt, kf, vf, pb, db);
+        back(32 * qt, pb, db, dk, dv);
+    }
+    __syncthreads();                                   // every wave is done with the images: they become slabs
+
+    // ---- epilogue: dK, dV of this wave's 32 keys through a private LDS slab -> whole 128-B rows; column sums in the partial-row
+    // layout of the streaming kernels (one row per 16 keys: this wave's sums go to the first of its two rows, zeros to the second)
+    {
+        char* slab = lds + wave * (32 * FZ_SLAB_STRIDE);
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int d = 32 * dh + 8 * jj + 4 * hh;
+                const bf16x4 wk = {f2bf(dk[dh][4 * jj] * p.scale), f2bf(dk[dh][4 * jj + 1] * p.scale), f2bf(dk[dh][4 * jj + 2] * p.scale),
+                                   f2bf(dk[dh][4 * jj + 3] * p.scale)};
+                const bf16x4 wv = {f2bf(dv[dh][4 * jj]), f2bf(dv[dh][4 * jj + 1]), f2bf(dv[dh][4 * jj + 2]), f2bf(dv[dh][4 * jj + 3])};
+                *reinterpret_cast<bf16x4*>(slab + kk * FZ_SLAB_STRIDE + d * 2) = wk;
+                *reinterpret_cast<bf16x4*>(slab + kk * FZ_SLAB_STRIDE + 128 + d * 2) = wv;
+            }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        {
+            const int key = lane >> 1, which = lane & 1;
+            const char* src = slab + key * FZ_SLAB_STRIDE + which * 128;
+            __bf16* dst = p.out + ((size_t)b * T + 256 * kh + 32 * wave + key) * ld + (1 + which) * D + h * HD;
+#pragma unroll
+            for (int v8 = 0; v8 < 8; ++v8)
+                *reinterpret_cast<u32x4*>(dst + 8 * v8) = *reinterpret_cast<const u32x4*>(src + 16 * v8);
+        }
+        if (p.colsum) {
+            const int nblk = (T + 63) >> 6, kb = 4 * kh + (wave >> 1);
+            float* row = p.colsum + (((size_t)b * nblk + kb) * 4 + 2 * (wave & 1)) * ld + h * HD;
+            float s0 = 0.f, s1 = 0.f;                  // lane l: columns 2 l, 2 l + 1 of the slab's 128 (dK 64 | dV 64)
+            for (int key = 0; key < 32; ++key) {
+                const bf16x2 v = *reinterpret_cast<const bf16x2*>(slab + key * FZ_SLAB_STRIDE + 4 * lane);
+                s0 += bf2f(v[0]);
+                s1 += bf2f(v[1]);
+            }
+            const int which = lane >> 5, d = (2 * lane) & 63;
+            *reinterpret_cast<f32x2*>(row + (1 + which) * D + d) = f32x2{s0, s1};
+            *reinterpret_cast<f32x2*>(row + ld + (1 + which) * D + d) = f32x2{0.f, 0.f};
+            if (kh == 0 && wave == 0) {                // the odd key: block nblk - 1, its first row; the three rows behind it: zeros
+                float* lr = p.colsum + (((size_t)b * nblk + nblk - 1) * 4) * ld + h * HD + (1 + which) * D + d;
+                *reinterpret_cast<f32x2*>(lr) = f32x2{lonekv[which * 64 + d], lonekv[which * 64 + d + 1]};
+#pragma unroll
+                for (int z = 1; z < 4; ++z) *reinterpret_cast<f32x2*>(lr + z * ld) = f32x2{0.f, 0.f};
+            }
+        }
+    }
+}

@@ -1,0 +1,76 @@
+"""Key-stationary dK / dV at T = 513 (attention_fused.h: attn_bwd_dkdv_ks_kernel) against the streaming kernel: results, then time.
+p4p_set_attention_variant(64) switches it off."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import p4p_amd
+from p4p_amd import ops, _lib
+if os.environ.get('P4P_DEBUG_LIB'):
+    _lib.LIB_PATH = os.path.abspath(os.environ['P4P_DEBUG_LIB'])
+lib = _lib.lib()
+
+
+def ref_grad(qkv, dout, B, T, H):
+    D = qkv.shape[1] // 3
+    qr = qkv.float().requires_grad_(True)
+    x = qr.reshape(B, T, 3, H, D // H).permute(2, 0, 3, 1, 4)
+    a = ((x[0] @ x[1].transpose(-2, -1)) * (D // H) ** -0.5).softmax(-1)
+    (a @ x[2]).transpose(1, 2).reshape(B * T, D).backward(dout.float())
+    return qr.grad
+
+
+ok = True
+T = 513
+for B, H in [(1, 1), (2, 3), (3, 12)]:
+    D = 64 * H
+    g = torch.Generator().manual_seed(T + B)
+    qkv = (torch.randn(B * T, 3 * D, generator=g) * 1.5).to(torch.bfloat16).cuda()
+    dout = torch.randn(B * T, D, generator=g).to(torch.bfloat16).cuda()
+    out, lse = ops.attention_fwd(qkv, B, T, H)
+    lib.p4p_set_attention_variant(64)
+    old, old_cs = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
+    old, old_cs = old.clone(), old_cs.clone()
+    lib.p4p_set_attention_variant(0)
+    new, new_cs = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
+    ref = ref_grad(qkv, dout, B, T, H)
+    sc = max(ref.abs().max().item(), 1.0)
+    e_old, e_new = (old.float() - ref).abs().max().item() / sc, (new.float() - ref).abs().max().item() / sc
+    d = (new.float() - old.float()).abs()
+    last = d.view(B, T, 3 * D)[:, T - 1].max().item()
+    cs_err = (new_cs.double() - new.double().sum(0)).abs().max().item() / max(new.float().abs().sum(0).max().item(), 1.0)
+    good = e_new <= 3e-2 and cs_err <= 1e-5 and torch.isfinite(new.float()).all().item() and torch.equal(new[:, :D], old[:, :D])
+    ok &= good
+    print(f'B={B} T={T} H={H}: err vs fp32 autograd old {e_old:.2e} new {e_new:.2e} | new-old dk {d[:, D:2 * D].max().item():.2e} dv {d[:, 2 * D:].max().item():.2e} '
+          f'last row {last:.2e} | colsum err {cs_err:.1e} | {"ok" if good else "FAIL"}', flush=True)
+if not ok:
+    sys.exit(1)
+B, H, D = 256, 12, 768
+g = torch.Generator().manual_seed(0)
+qkv = torch.randn(B * T, 3 * D, generator=g).to(torch.bfloat16).cuda()
+dout = torch.randn(B * T, D, generator=g).to(torch.bfloat16).cuda()
+out, lse = ops.attention_fwd(qkv, B, T, H)
+
+
+def timeit(f, n=10):
+    for _ in range(3): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1000 / n
+
+
+for rnd in range(3):
+    for v, name in ((64, 'streaming dK/dV'), (32, 'key-stationary no shift'), (0, 'key-stationary 3x12k'), ((1 << 8) + (20 << 10), 'key-stationary 2x20k'), ((3 << 8) + (10 << 10), 'key-stationary 4x10k')):
+        lib.p4p_set_attention_variant(v)
+        a = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, B, T, H))
+        b = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True))
+        print(f'round {rnd} {name:24s}: bwd {a:7.1f} us   with colsum {b:7.1f} us', flush=True)
+lib.p4p_set_attention_variant(0)
+ref = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
+ref = (ref[0].clone(), ref[1].clone())
+bad = 0
+for r in range(10):
+    got = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
+    bad += int(not (torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])))
+print('bitwise differing runs of 10:', bad)
