@@ -126,7 +126,8 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
     constexpr int NKS = L / 32;                       // 32-key contraction steps of the dQ product
     static_assert(NT == 1 || NT == 2 || NT == 4 || NT == 8, "8 output tiles must divide over the waves");
     __shared__ __attribute__((aligned(1024))) char lds[LY::TOTAL];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);          // scalar: tile picks, LDS-DMA destinations, output-tile ids stay in SGPRs
     const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
     const int T = p.T, D = p.D;                       // T = L + 1
     const size_t ld = (size_t)3 * D;
@@ -522,6 +523,16 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
 // everyone wait for), 60-80 spilled registers at the 256-VGPR limit and the exposed K / V fetch at the pair seam cost more than
 // the overlapped load phase returns.  Touching the next round's lines into L2 / Infinity Cache from this kernel was measured too:
 // 368 vs 360 us, no gain.  Not kept)
+//
+// (A second persistent form moved no byte through a register: every query tile of Q and of dO its OWN __shared__ array, so that
+// hipcc keeps no LDS read behind the LDS-DMA of the next pair's tile j -- issued right after the barrier of iteration j -- and raw
+// `s_waitcnt lgkmcnt(0); s_barrier` barriers in the loop (`__syncthreads()` drains the DMAs); the next pair's K image in a buffer of
+// its own, its V fragments / O rows loaded after the last use of their registers.  Correct (dqkv bit-identical to this kernel), the
+// ISA shows no vmcnt wait in the loop once the wave index is made scalar (`readfirstlane`: before that the DMAs' LDS destinations
+// sat in spilled VGPRs and every reload was a vmcnt(0) behind the DMA just issued: 395 us) -- and still 367 us against 307-311 us.
+// Stamps: 66k cycles per pair against 45k; the nine query tiles alone 39k against 22.5k EVEN WITH the in-loop DMAs compiled out,
+// at 256 VGPRs + 54 spills against 214 and none.  Whatever makes the same loop body 1.7x slower inside the persistent kernel
+// (register-limited scheduling is the suspect) was not found in the time given to it; the kernel is not in the tree.)
 
 // ================================================================================================================================
 // dK / dV for T = 32 NT + 1 with 8 < NT <= 16 (T = 513: N = 2048 points, the point north_star states its targets at), key-stationary
@@ -550,7 +561,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkdv_ks_kernel(AttnParams p) 
     constexpr int L = LY::L, ROWS = LY::ROWS, NW = 8, KH = NT / 8;
     static_assert(NT % 8 == 0, "whole key halves of 8 waves");
     __shared__ __attribute__((aligned(1024))) char lds[LY::TOTAL];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int kh = blockIdx.x % KH, bh = blockIdx.x / KH, b = bh / p.H, h = bh - b * p.H;
     const int T = p.T, D = p.D;                       // T = L + 1
     const size_t ld = (size_t)3 * D;

@@ -5,10 +5,12 @@ import ctypes, os, subprocess, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, 'adapting-2d-vits-for-3d-point-cloud-understanding_amd', 'csrc')
-so = '/tmp/libp4p_fzstamps.so'
-subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '-shared', '--offload-arch=gfx950', '-ffp-contract=off',
-                       '-fno-honor-nans', '-fno-slp-vectorize', '-Wno-unused-value', '-Wno-pass-failed', '-DP4P_FZ_STAMPS', '-I', CS,
-                       os.path.join(CS, 'attention.hip'), '-x', 'hip', os.path.join(CS, 'capi.cpp'), '-o', so])
+so = os.environ.get('P4P_STAMPS_LIB', '/tmp/libp4p_fzstamps.so')       # a prebuilt diagnostic library (tools/build_stamps.sh), or build here
+if 'P4P_STAMPS_LIB' not in os.environ:
+    extra = [a for a in sys.argv[1:] if a.startswith('-D')]
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '-shared', '--offload-arch=gfx950', '-ffp-contract=off',
+                           '-fno-honor-nans', '-fno-slp-vectorize', '-Wno-unused-value', '-Wno-pass-failed', '-DP4P_FZ_STAMPS', '-I', CS] + extra +
+                          [os.path.join(CS, 'attention.hip'), '-x', 'hip', os.path.join(CS, 'capi.cpp'), '-o', so])
 lib = ctypes.CDLL(so)
 B, T, H = 256, 257, 12
 D = 64 * H
@@ -33,3 +35,4 @@ print('mean s_memtime ticks since the workgroup started (wave 0), over', B * H, 
 for k, n in enumerate(names):
     print(f'  {n:28s} {float(rel[:, k].mean()):10.0f}')
 print('kernel span', float(raw[:, 6].max() - raw[:, 0].min()), 'ticks; sum of lifetimes / 256 CUs', float(rel[:, 6].sum() / 256))
+
