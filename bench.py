@@ -170,6 +170,45 @@ def _pmc_traffic(kernel_tag):
     return None, None
 
 
+def live_pmc_traffic(kernel_substr, timeout_s=150):
+    """HBM-side bytes per launch of one kernel, collected NOW: two child runs of this script under rocprofv3 (`--pmc FETCH_SIZE`,
+    then `--pmc WRITE_SIZE`: the two do not fit one pass; counters alone with --kernel-trace, as the pool's rules ask), one warm-up
+    + one step each, corrected as MI355X_MICROARCH.md prescribes for gfx950 (the counters are in KB; FETCH_SIZE reports half of
+    the bytes of wide coalesced reads).  Returns (bytes, note) or (None, reason)."""
+    import csv, glob, shutil, subprocess, tempfile
+    if shutil.which('rocprofv3') is None:
+        return None, 'rocprofv3 not found'
+    tmp = tempfile.mkdtemp(prefix='p4p_pmc_', dir='/tmp')
+    res = {}
+    try:
+        for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = os.path.join(tmp, ctr)
+            cmd = ['rocprofv3', '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d', out, '--',
+                   sys.executable, os.path.abspath(__file__), '--steps', '1', '--warmup', '1', '--no-cpu-baseline', '--no-roofline',
+                   '--no-north-star', '--no-pmc']
+            env = dict(os.environ, TMPDIR='/tmp')
+            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            files = glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f'rocprofv3 --pmc {ctr} failed (rc {r.returncode})'
+            tot, n = 0.0, 0
+            with open(files[0]) as fh:
+                for row in csv.DictReader(fh):
+                    if row.get('Counter_Name') == ctr and kernel_substr in row.get('Kernel_Name', ''):
+                        tot += float(row['Counter_Value'])
+                        n += 1
+            if n == 0:
+                return None, f'{kernel_substr} not in the {ctr} pass'
+            res[ctr] = (tot / n * 1024.0, n)
+    except Exception as e:                               # a profiler that is not usable here must not cost the benchmark line
+        return None, f'{type(e).__name__}: {e}'
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch, write = 2.0 * res['FETCH_SIZE'][0], res['WRITE_SIZE'][0]
+    return fetch + write, (f'bytes/launch collected in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two child passes of this '
+                           f'script ({res["FETCH_SIZE"][1]} launches each), FETCH x2 (gfx950) = {fetch * 1e-6:.0f} MB + {write * 1e-6:.0f} MB written')
+
+
 def instrumented_roofline(stepper, batch, steps, measure=True, attn_dims=None):
     """Rooflines measured live: the library brackets exactly the launches of one kind with HIP events on the launch
     stream (include/p4p_hip.h: p4p_prof_enable / p4p_prof_collect) during `steps` extra training steps per kind;
@@ -424,6 +463,7 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--bucket-mb', type=float, default=None,
                     help='gradient all-reduce bucket size (default: one bucket per transformer block, 28 MB for ViT-B)')
+    ap.add_argument('--no-pmc', action='store_true', help='do not collect roofline.traffic live (two short rocprofv3 --pmc child runs)')
     ap.add_argument('--no-north-star', action='store_true',
                     help='skip the extra N=2048, B=256 measurement (the point north_star states its targets at)')
     args = ap.parse_args()
@@ -497,6 +537,13 @@ def main():
             roof['index_ops'] = index_ops_roofline(args.batch, args.points, args.points // 4, 16, device)
         log('instrumented roofline pass done')
     ar_wait = allreduce_exposed_ms(stepper, batch) if distributed else None
+    if rank == 0 and roof is not None and world == 1 and default_config and not args.no_pmc:
+        live, note = live_pmc_traffic('gemm_wgrad3_kernel')
+        if live is not None:
+            roof['traffic'], roof['traffic_note'] = live, note
+        else:
+            roof['traffic_note'] = (roof.get('traffic_note') or '') + f' (live collection skipped: {note})'
+        log('PMC traffic: ' + note)
 
     # ---- the point north_star states its utilisation targets at: N=2048, B=256, ViT-B/12, one GPU
     ns = None

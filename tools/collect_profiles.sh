@@ -11,8 +11,8 @@ python3 $ROOT/bench.py --steps 10 --warmup 3 > $OUT/bench_N1.json 2> $OUT/bench_
 echo "bench done"
 python3 $ROOT/bench.py --workload apf --steps 10 --warmup 3 > $OUT/apf_bench_N1.json 2> $OUT/apf_bench_N1.err
 echo "apf bench done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_n1024 -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-north-star > $OUT/prof_n1024.json 2> /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_n2048 -- python3 $ROOT/bench.py --points 2048 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/prof_n2048.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_n1024 -- python3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-north-star --no-pmc > $OUT/prof_n1024.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_n2048 -- python3 $ROOT/bench.py --points 2048 --steps 10 --warmup 3 --no-cpu-baseline --no-pmc > $OUT/prof_n2048.json 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_apf -- python3 $ROOT/bench.py --workload apf --steps 10 --warmup 3 --no-cpu-baseline > $OUT/prof_apf.json 2> /dev/null
 echo "kernel stats done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-north-star > /dev/null 2>&1
