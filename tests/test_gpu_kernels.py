@@ -450,6 +450,42 @@ def test_attention_fwd_bwd(B, T, H):
         torch.testing.assert_close(out2.float(), _attn_ref(spike, B, T, H), rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize('B,T,H', [(3, 65, 2), (7, 129, 5), (2, 257, 12), (37, 257, 3), (2, 513, 12), (9, 513, 2)])
+def test_attention_backward_fused_kernels_against_the_two_kernel_path(B, T, H):
+    """Round 3: attn_bwd_fused_kernel (T = 65 / 129 / 257: one kernel for dQ, dK, dV) and attn_bwd_dkdv_ks_kernel (T = 513) against
+    the kernels they replace, switched back in through the tools' variant switch: the same arithmetic contract (P and dS rounded to
+    bf16 where they enter a product), so every element within a couple of bf16 ulps of the other path's (a single flipped
+    numerator), the same error against fp32 autograd, and the column sums = the sums of what was stored."""
+    from p4p_amd import _lib
+    lib = _lib.lib()
+    D = 64 * H
+    g = torch.Generator().manual_seed(1000 * T + B)
+    qkv = (torch.randn(B * T, 3 * D, generator=g) * 1.5).to(torch.bfloat16).to(DEV)
+    dout = torch.randn(B * T, D, generator=g).to(torch.bfloat16).to(DEV)
+    out, lse = ops.attention_fwd(qkv, B, T, H)
+    try:
+        lib.p4p_set_attention_variant(8 | 64)           # bit 3: no fused backward; bit 6: no key-stationary dK/dV
+        old, old_cs = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
+        old, old_cs = old.clone(), old_cs.clone()
+    finally:
+        lib.p4p_set_attention_variant(0)
+    new, new_cs = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
+    assert torch.isfinite(new.float()).all()
+    d = (new.float() - old.float()).abs()
+    tol = 4 * 2.0 ** -8 * torch.maximum(old.float().abs(), new.float().abs()) + 1e-3
+    assert (d <= tol).all(), float((d - tol).max())
+    assert float((d > 0).float().mean()) < 0.02        # and almost all elements are bit-identical
+    qr = qkv.float().requires_grad_(True)
+    _attn_ref(qr, B, T, H).backward(dout.float())
+    sc = max(qr.grad.abs().max().item(), 1.0)
+    assert (new.float() - qr.grad).abs().max().item() <= 3e-2 * sc
+    want = new.double().sum(0)
+    assert (new_cs.double() - want).abs().max().item() <= 1e-5 * max(new.float().abs().sum(0).max().item(), 1.0)
+    # the odd row (cls token: the last one) has the same treatment as every other row
+    last = d.view(B, T, 3 * D)[:, T - 1]
+    assert (last <= tol.view(B, T, 3 * D)[:, T - 1]).all()
+
+
 @pytest.mark.parametrize('B,T,runs', [(128, 513, 40), (256, 257, 20), (8, 2049, 10)])
 def test_attention_backward_is_bitwise_reproducible_under_load(B, T, runs):
     """A chip-filling launch repeated many times gives the same bits every time.  Regression for a barrier in the streaming
