@@ -1305,18 +1305,7 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
         P4P_LAUNCH_CHECK();
     }
     dim3 grid = attn_grid(B, T, H);
-    if (res) hipLaunchKernelGGL(attn_bwd_dq_res_kernel, dim3(B * H), dim3(RES_NW * 64), 0, st, p);
-    else if (dq_q)
-        hipLaunchKernelGGL(attn_bwd_dq_q_kernel<2>, dim3((unsigned)(ceil_div((long long)B * H, 8) * 8 * ceil_div(T, 128))),
-                           dim3(ATT_THREADS), 0, st, p);
-    else hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(ATT_THREADS), 0, st, p);
-    P4P_LAUNCH_CHECK();
-    if (res && res_dkdv) {
-        hipLaunchKernelGGL(attn_bwd_dkdv_res_kernel, dim3(B * H), dim3(RES_DKDV_NW * 64), 0, st, p);
-        P4P_LAUNCH_CHECK();
-        return 0;
-    }
-    if (T == 513 && !(g_attn_variant & 64)) {            // key-stationary dK / dV with Q, dO resident (attention_fused.h); bit 6: off
+    if (T == 513 && !(g_attn_variant & 64)) {            // streaming dQ (+ delta), then key-stationary dK / dV with Q, dO resident: attention_fused.h
         static int ncu = 0;
         if (!ncu) {
             int dev = 0;
@@ -1326,7 +1315,20 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
         p.stagger_n = ncu; p.stagger_phases = 3; p.stagger_cycles = 12 * 1024;
         if (g_attn_variant & 32) p.stagger_phases = 1;
         if (g_attn_variant >> 8) { p.stagger_phases = ((g_attn_variant >> 8) & 3) + 1; p.stagger_cycles = (g_attn_variant >> 10) * 1024; }
+        hipLaunchKernelGGL(attn_bwd_dq_q_kernel<2>, dim3((unsigned)(ceil_div((long long)B * H, 8) * 8 * ceil_div(T, 128))), dim3(ATT_THREADS), 0, st, p);
+        P4P_LAUNCH_CHECK();
         hipLaunchKernelGGL(attn_bwd_dkdv_ks_kernel<16>, dim3(B * H * 2), dim3(512), 0, st, p);
+        P4P_LAUNCH_CHECK();
+        return 0;
+    }
+    if (res) hipLaunchKernelGGL(attn_bwd_dq_res_kernel, dim3(B * H), dim3(RES_NW * 64), 0, st, p);
+    else if (dq_q)
+        hipLaunchKernelGGL(attn_bwd_dq_q_kernel<2>, dim3((unsigned)(ceil_div((long long)B * H, 8) * 8 * ceil_div(T, 128))),
+                           dim3(ATT_THREADS), 0, st, p);
+    else hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(ATT_THREADS), 0, st, p);
+    P4P_LAUNCH_CHECK();
+    if (res && res_dkdv) {
+        hipLaunchKernelGGL(attn_bwd_dkdv_res_kernel, dim3(B * H), dim3(RES_DKDV_NW * 64), 0, st, p);
         P4P_LAUNCH_CHECK();
         return 0;
     }

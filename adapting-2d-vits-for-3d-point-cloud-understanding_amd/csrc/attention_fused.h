@@ -794,3 +794,10 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkdv_ks_kernel(AttnParams p) 
         }
     }
 }
+
+// (The mirror image for dQ -- query-stationary: a wave's 32 queries with their Q / dO fragments, lse2, delta and dQ^T accumulators
+// in registers, K and V of the whole sequence resident in LDS, 17 key tiles without a barrier, the odd query's dQ row from
+// column-0 products, 164 VGPRs -- was built and verified (same errors as attn_bwd_dq_q_kernel<2>, bitwise reproducible): backward
+// 1,129-1,136 us with it against 1,109-1,122 us with the streaming dQ kernel in front of attn_bwd_dkdv_ks_kernel.  The streaming dQ
+// kernel already reads every K / V fragment for two query tiles; the barrier per tile it also pays is not what it waits for.
+// Not kept.)

@@ -37,9 +37,9 @@ for B, H in [(1, 1), (2, 3), (3, 12)]:
     d = (new.float() - old.float()).abs()
     last = d.view(B, T, 3 * D)[:, T - 1].max().item()
     cs_err = (new_cs.double() - new.double().sum(0)).abs().max().item() / max(new.float().abs().sum(0).max().item(), 1.0)
-    good = e_new <= 3e-2 and cs_err <= 1e-5 and torch.isfinite(new.float()).all().item() and torch.equal(new[:, :D], old[:, :D])
+    good = e_new <= 3e-2 and cs_err <= 1e-5 and torch.isfinite(new.float()).all().item()
     ok &= good
-    print(f'B={B} T={T} H={H}: err vs fp32 autograd old {e_old:.2e} new {e_new:.2e} | new-old dk {d[:, D:2 * D].max().item():.2e} dv {d[:, 2 * D:].max().item():.2e} '
+    print(f'B={B} T={T} H={H}: err vs fp32 autograd old {e_old:.2e} new {e_new:.2e} | new-old dq {d[:, :D].max().item():.2e} dk {d[:, D:2 * D].max().item():.2e} dv {d[:, 2 * D:].max().item():.2e} '
           f'last row {last:.2e} | colsum err {cs_err:.1e} | {"ok" if good else "FAIL"}', flush=True)
 if not ok:
     sys.exit(1)
@@ -61,7 +61,7 @@ def timeit(f, n=10):
 
 
 for rnd in range(3):
-    for v, name in ((64, 'streaming dK/dV'), (32, 'key-stationary no shift'), (0, 'key-stationary 3x12k'), ((1 << 8) + (20 << 10), 'key-stationary 2x20k'), ((3 << 8) + (10 << 10), 'key-stationary 4x10k')):
+    for v, name in ((64, 'streaming dK/dV'), (0, 'key-stationary dK/dV'), (32, 'the same, no shift')):
         lib.p4p_set_attention_variant(v)
         a = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, B, T, H))
         b = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True))
