@@ -96,7 +96,10 @@ int p4p_colreduce_f32(const float* part, float* out, int nrows, long long stride
 
 /* qkv [B*T,3D] bf16 (q|k|v, heads inside), out [B*T,D] bf16, lse2 [B,H,T] f32 (may be NULL for inference). */
 int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B, int T, int H, int D, float scale, void* stream);
-/* dqkv [B*T,3D] bf16 <- gradients; delta [B,H,T] f32 workspace.  colsum_partial (may be NULL):
+/* dqkv [B*T,3D] bf16 <- gradients; delta [B,H,T] f32 workspace (its contents after the call are unspecified: the kernels for
+   T = 65 / 129 / 257 -- one fused launch for dq, dk, dv, csrc/attention_fused.h -- do not use it).  Same arithmetic contract for
+   every T (P and dS rounded to bf16 where they enter a product, fp32 accumulation, no atomics: bitwise reproducible); which
+   kernels run depends on T only.  colsum_partial (may be NULL):
    [p4p_attention_colsum_rows(B,T)][3D] f32 per-wave column sums of dqkv, written by the same kernels; reduced with
    p4p_colreduce_f32 they are the gradient of the qkv bias (autograd of nn.Linear.bias in timm Attention.qkv). */
 int p4p_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse2, float* delta, void* dqkv,
