@@ -191,6 +191,24 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
     bf16x8 orow[4];
 #pragma unroll
     for (int v8 = 0; v8 < 4; ++v8) orow[v8] = *reinterpret_cast<const bf16x8*>(ob + (size_t)(32 * wave + kk) * D + 32 * hh + 8 * v8);
+    // ---- everything else the phase behind the barrier takes from global memory is asked for HERE, so that its latency runs out
+    // under the wait for the images: this wave's lse2 row and the odd key's K / V row as B operands (column 0; zeros elsewhere)
+    // (every lane loads the row -- one 16-B segment per half-wave -- and the lanes off column 0 are zeroed behind the barrier: a
+    // predicated load would be followed by a vmcnt(0) at the merge, i.e. by a wait for every LDS-DMA issued above)
+    const float lse_own = p.lse2[((size_t)b * p.H + h) * T + 32 * wave + kk];
+    bf16x8 klf[4], vlf[4];
+    {
+        const __bf16* krow = seq + (size_t)L * ld + D + h * HD + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            klf[s] = *reinterpret_cast<const bf16x8*>(krow + 16 * s);
+            vlf[s] = *reinterpret_cast<const bf16x8*>(krow + D + 16 * s);
+        }
+    }
+    bf16x4 klq[TPW];                                                  // the odd key's 4 columns of each dQ^T output tile of this wave
+#pragma unroll
+    for (int k = 0; k < TPW; ++k)
+        klq[k] = *reinterpret_cast<const bf16x4*>(seq + (size_t)L * ld + D + h * HD + 16 * ((wave + NT * k) & 3) + 4 * (lane >> 4));
     // ---- the odd row against itself, and its statistics: five 64-vectors, one column per lane of wave 0 (the pair (L, L) is the
     // only part of the last query tile's column of the odd key that is not padding: no MFMA tile for it)
     if (wave == 0) {
@@ -236,7 +254,7 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
         lane_swap32(s, s2);                            // lanes l and l + 32 hold the two halves of one row
         if (hh == 0) {
             ndel[row] = -(s + s2);
-            nlse[row] = -p.lse2[((size_t)b * p.H + h) * T + row];
+            nlse[row] = -lse_own;
         }
     }
 
@@ -250,13 +268,11 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
 
     // ---- the odd key (row L) against every query tile: column 0 of the B operands holds it, the other columns are zero
     {
-        bf16x8 klf[4], vlf[4];
-        const __bf16* krow = seq + (size_t)L * ld + D + h * HD + 8 * hh;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const bf16x8 z = {};
-            klf[s] = kk == 0 ? *reinterpret_cast<const bf16x8*>(krow + 16 * s) : z;
-            vlf[s] = kk == 0 ? *reinterpret_cast<const bf16x8*>(krow + D + 16 * s) : z;
+            klf[s] = kk == 0 ? klf[s] : z;
+            vlf[s] = kk == 0 ? vlf[s] : z;
         }
         f32x16 dkl[2], dvl[2];
 #pragma unroll
@@ -359,13 +375,11 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) dswb[jj] = dsx + (32 * wave + kk) * 64 + (((2 * jj + hh) ^ fz_sigd(kk)) << 3);
     const char* dstb[TPW];
-    bf16x4 klq[TPW];                                                  // the odd key's 4 columns of each output tile
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
         const int u = wave + NT * k, a = u >> 2, bq = u & 3;
         const int klo = 4 * g + (i16 >> 2);
         dstb[k] = dsx + klo * 64 + (((4 * a + (i16 & 3)) ^ fz_sigd(klo)) << 3);
-        klq[k] = *reinterpret_cast<const bf16x4*>(seq + (size_t)L * ld + D + h * HD + 16 * bq + 4 * g);
     }
     const float* rcb = nlse + 4 * hh;                                 // row constants: + row0 + 8 jj (ndel: + ROWS)
     auto rowconst = [&](int arr_off, int row0) -> f32x16 {
@@ -466,10 +480,14 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
             // column sums of the STORED (rounded) dq | dk | dv over this (b, h): partial row `wave` of RES_COLSUM_ROWS
             float* row = p.colsum + ((size_t)b * RES_COLSUM_ROWS + wave) * ld + h * HD;
             float s0 = 0.f, s1 = 0.f;                  // lane l: columns 2 l, 2 l + 1 of the slab's 128 (dK 64 | dV 64)
+            bf16x2 cv[32];                             // all 32 reads in flight, then the sums in key order (rolled, hipcc waited for each read)
+#pragma unroll
+            for (int key = 0; key < 32; ++key) cv[key] = *reinterpret_cast<const bf16x2*>(slab + key * FZ_SLAB_STRIDE + 4 * lane);
+            __builtin_amdgcn_sched_barrier(0);         // (without it the scheduler sinks every read to its use again)
+#pragma unroll
             for (int key = 0; key < 32; ++key) {
-                const bf16x2 v = *reinterpret_cast<const bf16x2*>(slab + key * FZ_SLAB_STRIDE + 4 * lane);
-                s0 += bf2f(v[0]);
-                s1 += bf2f(v[1]);
+                s0 += bf2f(cv[key][0]);
+                s1 += bf2f(cv[key][1]);
             }
             const int which = lane >> 5, d = (2 * lane) & 63;
             if (wave == 0) {                           // the odd key's rows
@@ -619,6 +637,16 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkdv_ks_kernel(AttnParams p) 
             ndel[e] = e < T ? -del_b[e] : 0.f;
         }
     }
+    // ---- the odd key's K / V row as B operands (key half 0; column 0, zeros elsewhere): asked for ahead of the barrier
+    bf16x8 klf[4], vlf[4];
+    {
+        const __bf16* krow = seq + (size_t)L * ld + D + h * HD + 8 * hh;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {                  // (all lanes load, the lanes off column 0 are zeroed at use: attn_bwd_fused_kernel)
+            klf[s] = *reinterpret_cast<const bf16x8*>(krow + 16 * s);
+            vlf[s] = *reinterpret_cast<const bf16x8*>(krow + D + 16 * s);
+        }
+    }
     // ---- the odd row against itself (key half 0, wave 0): its share of dK[L], dV[L]
     if (kh == 0 && wave == 0) {
         const size_t rl = (size_t)L * ld + h * HD + lane;
@@ -693,13 +721,11 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkdv_ks_kernel(AttnParams p) 
 
     // ---- the odd key (key half 0): wave w takes query tiles w, w + 8, .. against it (column 0 of the B operands)
     if (kh == 0) {
-        bf16x8 klf[4], vlf[4];
-        const __bf16* krow = seq + (size_t)L * ld + D + h * HD + 8 * hh;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const bf16x8 z = {};
-            klf[s] = kk == 0 ? *reinterpret_cast<const bf16x8*>(krow + 16 * s) : z;
-            vlf[s] = kk == 0 ? *reinterpret_cast<const bf16x8*>(krow + D + 16 * s) : z;
+            klf[s] = kk == 0 ? klf[s] : z;
+            vlf[s] = kk == 0 ? vlf[s] : z;
         }
         f32x16 dkl[2], dvl[2];
 #pragma unroll
@@ -777,10 +803,14 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkdv_ks_kernel(AttnParams p) 
             const int nblk = (T + 63) >> 6, kb = 4 * kh + (wave >> 1);
             float* row = p.colsum + (((size_t)b * nblk + kb) * 4 + 2 * (wave & 1)) * ld + h * HD;
             float s0 = 0.f, s1 = 0.f;                  // lane l: columns 2 l, 2 l + 1 of the slab's 128 (dK 64 | dV 64)
+            bf16x2 cv[32];                             // all 32 reads in flight, then the sums in key order (rolled, hipcc waited for each read)
+#pragma unroll
+            for (int key = 0; key < 32; ++key) cv[key] = *reinterpret_cast<const bf16x2*>(slab + key * FZ_SLAB_STRIDE + 4 * lane);
+            __builtin_amdgcn_sched_barrier(0);         // (without it the scheduler sinks every read to its use again)
+#pragma unroll
             for (int key = 0; key < 32; ++key) {
-                const bf16x2 v = *reinterpret_cast<const bf16x2*>(slab + key * FZ_SLAB_STRIDE + 4 * lane);
-                s0 += bf2f(v[0]);
-                s1 += bf2f(v[1]);
+                s0 += bf2f(cv[key][0]);
+                s1 += bf2f(cv[key][1]);
             }
             const int which = lane >> 5, d = (2 * lane) & 63;
             *reinterpret_cast<f32x2*>(row + (1 + which) * D + d) = f32x2{s0, s1};
