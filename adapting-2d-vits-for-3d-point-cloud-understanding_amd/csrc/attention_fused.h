@@ -100,6 +100,29 @@ __device__ __forceinline__ f32x16 fz_rowconst(const float* arr, int row0, int la
 #define FZ_STAMP(k) do { } while (0)
 #endif
 
+// Sources of the 1-KiB LDS-DMA pieces (8 rows x 128 B of one image) as a UNIFORM base (SGPRs) + a 32-bit per-lane byte offset, so
+// that a piece costs a handful of scalar instructions (global_load_lds_dwordx4 v, s[base]): written with per-lane 64-bit
+// pointers the 13-17 DMAs of a wave took ~35 instructions each (64-bit multiplies, a branch per image), ~5 % of a workgroup's life.
+// Row r = 8 p + rin of a piece p: fz_sig(r) = ((rin >> 1) & 3) | ((((rin >> 1) ^ (p >> 1)) & 1) << 2), i.e. two lane offsets per
+// row stride, picked by the parity of p >> 1; the piece behind row L (rows past T - 1 repeat row T - 1) has no row term.
+struct FzSrc {
+    unsigned par[2], last;                            // lane offsets: pieces with (p >> 1) even / odd; the piece of rows L .. L + 7
+};
+__device__ __forceinline__ FzSrc fz_src(int lane, unsigned row_bytes) {
+    const int rin = lane >> 3;
+    FzSrc o;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int sig = ((rin >> 1) & 3) | ((((rin >> 1) ^ e) & 1) << 2);
+        o.par[e] = rin * row_bytes + (((lane & 7) ^ sig) << 4);
+    }
+    o.last = o.par[0] - rin * row_bytes;               // L / 8 = 4 NT: (p >> 1) even
+    return o;
+}
+__device__ __forceinline__ void fz_dma(const char* ubase, unsigned loff, char* dst) {
+    __builtin_amdgcn_global_load_lds(GLB_PTR(ubase + loff), LDS_PTR(dst), 16, 0, 0);
+}
+
 #define FZ_SLAB_STRIDE 272          // epilogue slab row: K 128 B | V 128 B | 16 B pad (bank spread of the 8-B writes)
 
 template <int NT>
@@ -158,18 +181,30 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
     {
         const int rin = lane >> 3;
         constexpr int NPC = L / 8 + 1;                 // pieces per image: rows 0 .. L + 7
-        for (int pc = wave; pc < 2 * NPC; pc += NT) {
-            const int isd = pc >= NPC, piece = isd ? pc - NPC : pc;
-            const int row = piece * 8 + rin;
-            const int r = row < T ? row : T - 1;
-            const int chunk = (lane & 7) ^ fz_sig(row);
-            const __bf16* src = isd ? dob + (size_t)r * D + chunk * 8 : seq + (size_t)r * ld + h * HD + chunk * 8;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR((isd ? dos : qs) + piece * 1024), 16, 0, 0);
+        const unsigned qrow = (unsigned)ld * 2, drow = (unsigned)D * 2;          // bytes per row of qkv / of dO
+        const FzSrc sq = fz_src(lane, qrow), sd = fz_src(lane, drow);
+        const char* qbase = reinterpret_cast<const char*>(seq + h * HD);
+        const char* dbase = reinterpret_cast<const char*>(dob);
+        const unsigned lk = rin * qrow + (((lane & 7) ^ rin) << 4);
+        const char* kbase = reinterpret_cast<const char*>(seq + D + h * HD);
+        static_assert(NPC == L / 8 + 1, "");
+#pragma unroll
+        for (int i = 0; i < L / 8 / NT; ++i) {          // 4 pieces of Q, of dO and of K per wave: running uniform bases, no branch
+            const int pc = wave + NT * i;
+            fz_dma(qbase + (size_t)(8 * pc) * qrow, ((pc >> 1) & 1) ? sq.par[1] : sq.par[0], qs + pc * 1024);
         }
-        const int chunk = (lane & 7) ^ rin;
-        for (int pc = wave; pc < L / 8; pc += NT)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(seq + (size_t)(pc * 8 + rin) * ld + D + h * HD + chunk * 8),
-                                             LDS_PTR(dsx + pc * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < L / 8 / NT; ++i) {
+            const int pc = wave + NT * i;
+            fz_dma(dbase + (size_t)(8 * pc) * drow, ((pc >> 1) & 1) ? sd.par[1] : sd.par[0], dos + pc * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < L / 8 / NT; ++i) {
+            const int pc = wave + NT * i;
+            fz_dma(kbase + (size_t)(8 * pc) * qrow, lk, dsx + pc * 1024);
+        }
+        if (wave == 0) fz_dma(qbase + (size_t)L * qrow, sq.last, qs + (L / 8) * 1024);              // rows L .. L + 7: row L eight times
+        if (wave == NT - 1) fz_dma(dbase + (size_t)L * drow, sd.last, dos + (L / 8) * 1024);
         // rows L + 8 .. L + 31 of both images: zeros (finite operands for the padded rows of the last query tile)
         for (int e = t; e < 2 * 24 * 8; e += NT * 64) {
             char* img = e >= 24 * 8 ? dos : qs;
@@ -602,16 +637,24 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkdv_ks_kernel(AttnParams p) 
 
     // ---- stage Q, dO (1-KiB pieces of 8 rows; rows L + 1 .. L + 7 repeat row L, the rest of the last tile is zero)
     {
-        const int rin = lane >> 3;
         constexpr int NPC = L / 8 + 1;
-        for (int pc = wave; pc < 2 * NPC; pc += NW) {
-            const int isd = pc >= NPC, piece = isd ? pc - NPC : pc;
-            const int row = piece * 8 + rin;
-            const int r = row < T ? row : T - 1;
-            const int chunk = (lane & 7) ^ fz_sig(row);
-            const __bf16* src = isd ? dob + (size_t)r * D + chunk * 8 : seq + (size_t)r * ld + h * HD + chunk * 8;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR((isd ? dos : qs) + piece * 1024), 16, 0, 0);
+        const unsigned qrow = (unsigned)ld * 2, drow = (unsigned)D * 2;          // uniform base + 32-bit lane offset: fz_src
+        const FzSrc sq = fz_src(lane, qrow), sd = fz_src(lane, drow);
+        const char* qbase = reinterpret_cast<const char*>(seq + h * HD);
+        const char* dbase = reinterpret_cast<const char*>(dob);
+        static_assert(NPC == L / 8 + 1, "");
+#pragma unroll
+        for (int i = 0; i < L / 8 / NW; ++i) {          // 8 pieces of Q and of dO per wave
+            const int pc = wave + NW * i;
+            fz_dma(qbase + (size_t)(8 * pc) * qrow, ((pc >> 1) & 1) ? sq.par[1] : sq.par[0], qs + pc * 1024);
         }
+#pragma unroll
+        for (int i = 0; i < L / 8 / NW; ++i) {
+            const int pc = wave + NW * i;
+            fz_dma(dbase + (size_t)(8 * pc) * drow, ((pc >> 1) & 1) ? sd.par[1] : sd.par[0], dos + pc * 1024);
+        }
+        if (wave == 0) fz_dma(qbase + (size_t)L * qrow, sq.last, qs + (L / 8) * 1024);              // rows L .. L + 7: row L eight times
+        if (wave == NW - 1) fz_dma(dbase + (size_t)L * drow, sd.last, dos + (L / 8) * 1024);
         for (int e = t; e < 2 * 24 * 8; e += NW * 64) {
             char* img = e >= 24 * 8 ? dos : qs;
             const int ee = e >= 24 * 8 ? e - 24 * 8 : e;
@@ -824,6 +867,18 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkdv_ks_kernel(AttnParams p) 
         }
     }
 }
+
+// (The same kernel with the load phase PIPELINED was built and verified in round 3 -- the Q / dO images in four chunks of four query
+// tiles, each chunk its own __shared__ array, all LDS-DMAs issued up front in chunk order, the loop started behind chunk 0 and passing
+// a counted `s_waitcnt vmcnt(13 / 9 / 5 / 0)` + raw `s_barrier` in front of tiles 4, 8, 12; the odd key's phase moved behind the loop,
+// the row statistics fetched by 4-byte LDS-DMAs with their signs folded into the products (-V as the dP operand, +delta as the
+// chain's start).  dqkv and the column sums bit-identical to this kernel; backward at T = 513, B = 256, H = 12 in one call:
+// 1,119-1,128 us against 1,103-1,131 us.  Diagnostic builds of it: no image loaded at all 1,032-1,050 us (so the whole load phase is
+// worth 80 us of this kernel's ~570), only chunk 0 loaded 1,059-1,073, all chunks loaded but waited for up front 1,119-1,148 -- the
+// three later chunks cost their 55 us whether they are waited for at the start or at tiles 4 / 8 / 12.  Two things learnt on the
+// way, both from the ISA: with an LDS-DMA in the queue hipcc waits for ANY register filled by a plain global load with vmcnt(0)
+// (i.e. for every DMA behind it), and it puts vmcnt(0) in front of a builtin LDS store into an array that has a DMA outstanding --
+// a kernel that wants DMAs in flight across its first MFMAs needs inline-asm loads / stores for those, and raw barriers.  Not in the tree.)
 
 // (The mirror image for dQ -- query-stationary: a wave's 32 queries with their Q / dO fragments, lse2, delta and dQ^T accumulators
 // in registers, K and V of the whole sequence resident in LDS, 17 key tiles without a barrier, the odd query's dQ row from
