@@ -555,6 +555,29 @@ def test_global_feat_matches_torch():
     assert torch.equal(got2, torch.cat([x[:, 0, :], x[:, 1:, :].max(dim=1)[0]], dim=1))
 
 
+@pytest.mark.parametrize('B,T,D', [(3, 2, 64), (2, 3, 128), (2, 5, 64), (4, 6, 192), (2, 257, 768), (3, 130, 260), (2, 33, 6)])
+def test_global_feat_forward_edge_cases(B, T, D):
+    """The vectorised forward (four token slices per column quad, merged in LDS) against torch.max: value AND the index of the FIRST
+    maximum, with ties inside a slice and across slices, a column of -inf, a NaN (it wins), and a width that takes the
+    scalar kernel (D % 4 != 0)."""
+    from p4p_amd import ops as O
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    x = torch.randn(B, T, D, generator=g)
+    if T > 4:
+        x[0, 1, 0] = x[0, 2, 0] = 50.0            # tie across slices: token 1 wins
+        x[0, 4, 1] = x[0, 3, 1] = 50.0            # tie, the later slice holds the smaller index
+        x[1, 1:, 2] = float('-inf')               # nothing but -inf: the first token
+        x[1, 3, 3] = float('nan'); x[1, 2, 3] = 60.0          # a NaN beats everything
+    if T > 9:
+        x[0, 9, 5] = x[0, 5, 5] = 50.0            # tie inside one slice (tokens 5 and 9)
+    x = x.to(DEV)
+    mx, arg, cls = O.global_feat_fwd(x, want_max=True, want_cls=True)
+    wv, wi = x[:, 1:, :].max(dim=1)
+    assert torch.equal(torch.nan_to_num(mx, nan=12345.0), torch.nan_to_num(wv, nan=12345.0))
+    assert torch.equal(arg.long(), wi + 1)
+    assert torch.equal(cls, x[:, 0, :])
+
+
 def test_pos_mlp0_matches_torch():
     """GELU(Linear(3,128)) of PointViT.pos_embed and its weight / bias gradients against torch (fp32)."""
     from p4p_amd import functional as F
