@@ -12,7 +12,7 @@ if 'P4P_STAMPS_LIB' not in os.environ:
                            '-fno-honor-nans', '-fno-slp-vectorize', '-Wno-unused-value', '-Wno-pass-failed', '-DP4P_FZ_STAMPS', '-I', CS] + extra +
                           [os.path.join(CS, 'attention.hip'), '-x', 'hip', os.path.join(CS, 'capi.cpp'), '-o', so])
 lib = ctypes.CDLL(so)
-B, T, H = 256, 257, 12
+B, T, H = int(os.environ.get('FZ_B', 256)), 257, int(os.environ.get('FZ_H', 12))      # FZ_B=2: 24 workgroups, the chip to themselves
 D = 64 * H
 g = torch.Generator().manual_seed(0)
 qkv = torch.randn(B * T, 3 * D, generator=g).to(torch.bfloat16).cuda()
