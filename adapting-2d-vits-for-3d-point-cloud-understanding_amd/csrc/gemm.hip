@@ -432,6 +432,17 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
     *reinterpret_cast<f32x4*>(out + e) = s;
 }
 
+// out[e] = sum_s slabs[s][e] in the fixed order s = 0, 1, ..: the positional-embedding gradient as the sum of the L block-input
+// gradients the encoder backward leaves in L slabs (functional._EncoderFn.backward), one pass instead of a read-modify-write per block
+extern "C" int p4p_sum_slabs_f32(const float* slabs, float* out, long long n, int nslabs, void* stream) {
+    P4P_CHECK(slabs && out && n >= 4 && n % 4 == 0 && nslabs >= 1, "p4p_sum_slabs_f32: bad arguments (n=%lld, nslabs=%d)", n, nslabs);
+    P4P_CHECK(((reinterpret_cast<size_t>(slabs) | reinterpret_cast<size_t>(out)) & 15) == 0, "p4p_sum_slabs_f32: 16-byte alignment");
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)ceil_div(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, slabs, out, n,
+                       nslabs, 0.f);
+    P4P_LAUNCH_CHECK();
+    return 0;
+}
+
 static bool wgrad_use_v3(int M, int N, int K) { return N % W3_BN == 0 && K % W3_BK == 0 && M >= 4096; }
 static int g_wgrad_wide = 2;      // 0: 256x128 tiles, 1: 256x256, 2: 256x256 with the hand-interleaved issue order
 extern "C" int p4p_set_wgrad_wide(int v) { int o = g_wgrad_wide; g_wgrad_wide = v; return o; }

@@ -69,7 +69,8 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_fwd_kernel(const float* 
     }
 }
 
-// dx (+)= rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat));  partial[blk][0][c] = sum dy*xhat,
+// dx = accumulate * dx_in + rstd * (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat))  (dx_in may be dx itself: in place; no
+// __restrict__ conflict is exploited on that pair -- each element is read once, then written);  partial[blk][0][c] = sum dy*xhat,
 // partial[blk][1][c] = sum dy, partial[blk][2][c] = sum of the OUTPUT dx (the bias gradient of the Linear that
 // produced this residual stream: proj.bias / fc2.bias) over the rows this block handled.
 template <int J>
@@ -78,8 +79,8 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(const void* _
                                                                     const float* __restrict__ mean,
                                                                     const float* __restrict__ rstd,
                                                                     const float* __restrict__ gamma,
-                                                                    float* __restrict__ dx, int accumulate,
-                                                                    __bf16* __restrict__ dx_bf16,
+                                                                    float* dx, const float* dx_in,
+                                                                    int accumulate, __bf16* __restrict__ dx_bf16,
                                                                     float* __restrict__ dacc, int dacc_init,
                                                                     float* __restrict__ partial, int M, int D) {
     __shared__ float red[LN_THREADS / 64][3][256 * J];
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(LN_THREADS) void layernorm_bwd_kernel(const void* _
             const int c = j * 256 + lane * 4;
             if (c < D) {
                 f32x4 o = (d[j] * g[j] - m1 - xh[j] * m2) * rs;
-                if (accumulate) o += (float)accumulate * *reinterpret_cast<const f32x4*>(dx + base + c);   // 1 or 2 (a residual used twice)
+                if (accumulate) o += (float)accumulate * *reinterpret_cast<const f32x4*>(dx_in + base + c);   // 1 or 2 (a residual used twice)
                 *reinterpret_cast<f32x4*>(dx + base + c) = o;
                 ao[j] += o;
                 if (dx_bf16) {
@@ -243,9 +244,10 @@ extern "C" int p4p_layernorm_fwd(const float* x, const float* pos, const float* 
 // partial: [LN_BWD_BLOCKS][3][D] floats of workspace; dgamma/dbeta/dxsum = beta_acc * old + column sums
 // (dgamma, dbeta, dxsum contiguous as [3][D] or [2][D] takes one reduce launch).
 extern "C" int p4p_layernorm_bwd(const void* dy, int dy_is_f32, const float* xin, const float* mean,
-                                 const float* rstd, const float* gamma, float* dx, int accumulate_dx,
+                                 const float* rstd, const float* gamma, float* dx, const float* dx_in, int accumulate_dx,
                                  void* dx_bf16, float* dacc, int dacc_init, float* partial, float* dgamma,
                                  float* dbeta, float* dxsum, float beta_acc, int M, int D, void* stream) {
+    if (!dx_in) dx_in = dx;                              // in place
     P4P_CHECK(dy && xin && mean && rstd && gamma && dx && partial, "p4p_layernorm_bwd: null pointer");
     P4P_CHECK(M >= 1 && D >= 4 && D % 4 == 0 && D <= 2048, "p4p_layernorm_bwd: bad sizes M=%d D=%d", M, D);
     hipStream_t st = (hipStream_t)stream;
@@ -254,7 +256,7 @@ extern "C" int p4p_layernorm_bwd(const void* dy, int dy_is_f32, const float* xin
     dim3 grid(blocks), blk(LN_THREADS);
     int J = ceil_div(D, 256);
 #define LN_BWD(JJ) hipLaunchKernelGGL(layernorm_bwd_kernel<JJ>, grid, blk, 0, st, dy, dy_is_f32, xin, mean, rstd, gamma, \
-                                      dx, accumulate_dx, (__bf16*)dx_bf16, dacc, dacc_init, partial, M, D)
+                                      dx, dx_in, accumulate_dx, (__bf16*)dx_bf16, dacc, dacc_init, partial, M, D)
     if (J <= 1) LN_BWD(1); else if (J <= 2) LN_BWD(2); else if (J <= 3) LN_BWD(3); else if (J <= 4) LN_BWD(4); else LN_BWD(8);
 #undef LN_BWD
     P4P_LAUNCH_CHECK();

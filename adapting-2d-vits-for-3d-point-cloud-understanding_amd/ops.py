@@ -169,13 +169,18 @@ def layernorm_fwd(x, gamma, beta, eps=1e-6, pos=None, want_sum=False, out_f32=Fa
 
 
 def layernorm_bwd(dy, xin, mean, rstd, gamma, dx=None, dgamma=None, dbeta=None, beta_acc=0.0, dx_bf16=None,
-                  dacc=None, dacc_init=False, want_dxsum=False, dx_factor=1, want_params=True):
-    """Returns (dx, dgamma, dbeta); if dx is given the LN gradient is ADDED to dx_factor * dx in place (dx_factor 1 or 2).
+                  dacc=None, dacc_init=False, want_dxsum=False, dx_factor=1, want_params=True, dx_in=None):
+    """Returns (dx, dgamma, dbeta); if dx is given the LN gradient is ADDED to dx_factor * dx in place (dx_factor 1 or 2) -- or,
+    with dx_in, dx = dx_factor * dx_in + the LN gradient (dx written, dx_in left alone).
     dx_bf16 gets a bf16 copy of the result, dacc accumulates it (positional-embedding gradient)."""
     M, D = xin.shape
     _chk(dy, 'dy', None, 2)
     if dy.dtype not in (torch.float32, torch.bfloat16):
         raise RuntimeError('layernorm_bwd: dy must be f32 or bf16')
+    if dx_in is not None:
+        _chk(dx_in, 'dx_in', torch.float32, 2)
+        if dx is None or dx_in.shape != dx.shape or dx.shape != xin.shape:
+            raise RuntimeError('layernorm_bwd: dx_in needs a dx of the same shape to write to')
     acc = dx is not None
     if dx_factor not in (1, 2):
         raise RuntimeError('layernorm_bwd: dx_factor must be 1 or 2')
@@ -191,11 +196,23 @@ def layernorm_bwd(dy, xin, mean, rstd, gamma, dx=None, dgamma=None, dbeta=None, 
     rows = L.call_int('p4p_layernorm_bwd_partial_rows')
     part = _workspace('lnbwd', rows * 3 * D, xin.device)
     L.call('p4p_layernorm_bwd', L.ptr(dy), int(dy.dtype == torch.float32), L.ptr(xin), L.ptr(mean), L.ptr(rstd),
-           L.ptr(gamma), L.ptr(dx), int(dx_factor) if acc else 0, L.ptr(dx_bf16), L.ptr(dacc), int(dacc_init), L.ptr(part), L.ptr(dgamma),
+           L.ptr(gamma), L.ptr(dx), L.ptr(dx_in), int(dx_factor) if acc else 0, L.ptr(dx_bf16), L.ptr(dacc), int(dacc_init), L.ptr(part), L.ptr(dgamma),
            L.ptr(dbeta), L.ptr(dxsum), float(beta_acc), M, D, _stream())
     if want_dxsum:
         return dx, dgamma, dbeta, dxsum
     return dx, dgamma, dbeta
+
+
+def sum_slabs(slabs):
+    """slabs f32 (S, ...) contiguous -> their sum over S in the order 0, 1, .. (one pass)."""
+    _chk(slabs, 'slabs', torch.float32, None)
+    S = slabs.shape[0]
+    n = slabs[0].numel()
+    if n % 4:
+        raise RuntimeError('sum_slabs: slab size must be a multiple of 4')
+    out = torch.empty(slabs.shape[1:], dtype=torch.float32, device=slabs.device)
+    L.call('p4p_sum_slabs_f32', L.ptr(slabs), L.ptr(out), L.i64(n), int(S), _stream())
+    return out
 
 
 # ---------------------------------------------------------------- attention

@@ -19,9 +19,9 @@ extern "C" {
 #endif
 
 /* Bumped on every incompatible change of a signature below (2: p4p_clip_coef gained grad_scale, p4p_apf_group gained C;
- * 3: this round).  libp4p_hip.so is built separately from the Python package: the binding compares p4p_abi_version() with
+ * 3: the version check itself; 4: p4p_layernorm_bwd gained dx_in).  libp4p_hip.so is built separately from the Python package: the binding compares p4p_abi_version() with
  * this constant when it loads the library and refuses a stale build. */
-#define P4P_ABI_VERSION 3
+#define P4P_ABI_VERSION 4
 int p4p_abi_version(void);
 const char* p4p_last_error(void);
 
@@ -78,17 +78,20 @@ int p4p_wgrad_splits(int M, int N, int K);
  * (the `feats + pos_embed` of src/models/pix4point.py:255); y bf16 or f32; mean/rstd [M] (may be NULL). */
 int p4p_layernorm_fwd(const float* x, const float* pos, const float* gamma, const float* beta, float eps,
                       float* xsum, void* y, int y_is_f32, float* mean, float* rstd, int M, int D, void* stream);
-/* dx = accumulate_dx * dx + LN'(dy) with accumulate_dx in {0, 1, 2} (2: the residual stream enters its block twice,
- * src/models/apf_utils.py:232,292); dgamma/dbeta = beta_acc*old + sums (either may be NULL);
+/* dx = accumulate_dx * dx_in + LN'(dy) with accumulate_dx in {0, 1, 2} (2: the residual stream enters its block twice,
+ * src/models/apf_utils.py:232,292); dx_in NULL = dx (in place); dgamma/dbeta = beta_acc*old + sums (either may be NULL);
  * dxsum (may be NULL) = beta_acc*old + column sums of the resulting dx: the bias gradient of the Linear that wrote
  * this residual stream (proj.bias / fc2.bias), free of an extra pass.
  * dx_bf16 (may be NULL) receives a bf16 copy of dx (next GEMM operand); dacc (may be NULL) accumulates dx
  * (gradient of the positional embedding that is re-added before every block, pix4point.py:255).
  * partial: [p4p_layernorm_bwd_partial_rows()][3][D] f32 workspace. */
 int p4p_layernorm_bwd(const void* dy, int dy_is_f32, const float* xin, const float* mean, const float* rstd,
-                      const float* gamma, float* dx, int accumulate_dx, void* dx_bf16, float* dacc, int dacc_init,
-                      float* partial, float* dgamma, float* dbeta, float* dxsum, float beta_acc, int M, int D,
+                      const float* gamma, float* dx, const float* dx_in, int accumulate_dx, void* dx_bf16, float* dacc,
+                      int dacc_init, float* partial, float* dgamma, float* dbeta, float* dxsum, float beta_acc, int M, int D,
                       void* stream);
+/* out[n] = slabs[0][n] + slabs[1][n] + .. in that order (n % 4 == 0): the gradient of the positional embedding that is re-added
+ * before every block (pix4point.py:255) as the sum of the block-input gradients kept in nslabs slabs. */
+int p4p_sum_slabs_f32(const float* slabs, float* out, long long n, int nslabs, void* stream);
 int p4p_layernorm_bwd_partial_rows(void);
 int p4p_colreduce_f32(const float* part, float* out, int nrows, long long stride, int ncols, float beta, void* stream);
 

@@ -401,6 +401,27 @@ def test_layernorm_fwd_bwd(M, D):
     torch.testing.assert_close(db, br.grad, rtol=1e-4, atol=1e-3)
     dx2, _, _ = ops.layernorm_bwd(dy.to(torch.bfloat16), xs, mean, rstd, gamma)
     torch.testing.assert_close(dx2, xr.grad, rtol=2e-2, atol=2e-2)
+    # out of place (dx = dx_in + LN'(dy), dx_in left alone): the same values, bit for bit, as in place -- for both factors
+    for fac in (1, 2):
+        inplace, _, _ = ops.layernorm_bwd(dy, xs, mean, rstd, gamma, dx=base.clone(), dx_factor=fac)
+        src, dst = base.clone(), torch.full_like(base, float('nan'))
+        out, _, _ = ops.layernorm_bwd(dy, xs, mean, rstd, gamma, dx=dst, dx_in=src, dx_factor=fac)
+        assert out.data_ptr() == dst.data_ptr() and torch.equal(dst, inplace) and torch.equal(src, base)
+
+
+def test_sum_slabs_adds_in_slab_order():
+    """p4p_sum_slabs_f32: the positional-embedding gradient as ONE pass over the block-input gradients, summed in slab order (the order
+    the read-modify-write it replaces had): bit-equal to a sequential fp32 sum, not just close to it."""
+    g = torch.Generator().manual_seed(3)
+    for S, shape in ((1, (8, 4)), (3, (5, 12)), (12, (257, 768)), (24, (33, 1024))):
+        slabs = (torch.randn(S, *shape, generator=g) * torch.logspace(-3, 3, S).view(S, 1, 1)).to(DEV)
+        want = slabs[0].clone()
+        for k in range(1, S):
+            want = want + slabs[k]
+        got = ops.sum_slabs(slabs)
+        assert got.shape == want.shape and torch.equal(got, want)
+    with pytest.raises(RuntimeError):
+        ops.sum_slabs(torch.zeros(2, 3, 5, device=DEV))            # slab size not a multiple of 4
 
 
 # ------------------------------------------------------------------------------------------ attention
