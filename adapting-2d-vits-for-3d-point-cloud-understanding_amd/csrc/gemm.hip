@@ -426,8 +426,16 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
                                     int splits, float beta) {
     long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (e >= n) return;
-    f32x4 s = *reinterpret_cast<const f32x4*>(slabs + e);
-    for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)k * n + e);
+    // four loads in flight per thread (one at a time the kernel sat at ~5 TB/s on latency x occupancy); the additions keep the order 0, 1, ..
+    const float* q = slabs + e;
+    f32x4 s = *reinterpret_cast<const f32x4*>(q);
+    int k = 1;
+    for (; k + 3 < splits; k += 4) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(q + (size_t)k * n), a1 = *reinterpret_cast<const f32x4*>(q + (size_t)(k + 1) * n);
+        const f32x4 a2 = *reinterpret_cast<const f32x4*>(q + (size_t)(k + 2) * n), a3 = *reinterpret_cast<const f32x4*>(q + (size_t)(k + 3) * n);
+        s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(q + (size_t)k * n);
     if (beta != 0.f) s += beta * *reinterpret_cast<const f32x4*>(out + e);
     *reinterpret_cast<f32x4*>(out + e) = s;
 }
