@@ -1291,7 +1291,15 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
         switch ((T - 1) / 32) {
             case 2: hipLaunchKernelGGL(attn_bwd_fused_kernel<2>, grid, dim3(2 * 64), 0, st, p); break;
             case 4: hipLaunchKernelGGL(attn_bwd_fused_kernel<4>, grid, dim3(4 * 64), 0, st, p); break;
-            default: hipLaunchKernelGGL(attn_bwd_fused_kernel<8>, grid, dim3(8 * 64), 0, st, p); break;
+            default:
+                // T = 257 (112 KB of LDS: one workgroup per CU anyway): ONE workgroup per CU walks its pairs (same body, a barrier
+                // between pairs; same box, B = 256, H = 12: 284-288 us against 304-310 us for a workgroup per pair, results
+                // bit-identical) -- no dispatch between pairs, and the start-time shift of the first round stays what it was set to.
+                // Bit 7 of the variant: a workgroup per pair.
+                if (!(g_attn_variant & 128) && B * H > ncu)
+                    hipLaunchKernelGGL((attn_bwd_fused_kernel<8, true>), dim3(ncu), dim3(8 * 64), 0, st, p);
+                else hipLaunchKernelGGL(attn_bwd_fused_kernel<8>, grid, dim3(8 * 64), 0, st, p);
+                break;
         }
         P4P_LAUNCH_CHECK();
         return 0;
@@ -1317,7 +1325,9 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
         if (g_attn_variant >> 8) { p.stagger_phases = ((g_attn_variant >> 8) & 3) + 1; p.stagger_cycles = (g_attn_variant >> 10) * 1024; }
         hipLaunchKernelGGL(attn_bwd_dq_q_kernel<2>, dim3((unsigned)(ceil_div((long long)B * H, 8) * 8 * ceil_div(T, 128))), dim3(ATT_THREADS), 0, st, p);
         P4P_LAUNCH_CHECK();
-        hipLaunchKernelGGL(attn_bwd_dkdv_ks_kernel<16>, dim3(B * H * 2), dim3(512), 0, st, p);
+        if (!(g_attn_variant & 128) && B * H * 2 > ncu)   // one workgroup per CU walks its work items (bit 7: a workgroup per item)
+            hipLaunchKernelGGL((attn_bwd_dkdv_ks_kernel<16, true>), dim3(ncu), dim3(512), 0, st, p);
+        else hipLaunchKernelGGL(attn_bwd_dkdv_ks_kernel<16>, dim3(B * H * 2), dim3(512), 0, st, p);
         P4P_LAUNCH_CHECK();
         return 0;
     }

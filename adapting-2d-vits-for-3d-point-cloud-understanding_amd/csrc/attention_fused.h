@@ -141,7 +141,7 @@ struct FzLds {
     static_assert(2 * IMG >= NT * 32 * FZ_SLAB_STRIDE, "epilogue slabs must fit the Q / dO images");
 };
 
-template <int NT>
+template <int NT, bool PERSIST = false>
 __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p) {
     using LY = FzLds<NT>;
     constexpr int L = LY::L, ROWS = LY::ROWS;
@@ -149,14 +149,8 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
     constexpr int NKS = L / 32;                       // 32-key contraction steps of the dQ product
     static_assert(NT == 1 || NT == 2 || NT == 4 || NT == 8, "8 output tiles must divide over the waves");
     __shared__ __attribute__((aligned(1024))) char lds[LY::TOTAL];
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);          // scalar: tile picks, LDS-DMA destinations, output-tile ids stay in SGPRs
-    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
     const int T = p.T, D = p.D;                       // T = L + 1
     const size_t ld = (size_t)3 * D;
-    const __bf16* seq = p.qkv + (size_t)b * T * ld;
-    const __bf16* dob = p.dout + (size_t)b * T * D + h * HD;
-    const __bf16* ob = p.o + (size_t)b * T * D + h * HD;
     const float c = p.scale * 1.4426950408889634f;
     char* qs = lds + LY::OFF_Q;
     char* dos = lds + LY::OFF_DO;
@@ -176,6 +170,19 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
         const unsigned long long t0 = __builtin_readcyclecounter();
         while (__builtin_readcyclecounter() - t0 < (unsigned long long)ph * p.stagger_cycles) __builtin_amdgcn_s_sleep(16);
     }
+    // (PERSIST, an experiment: one workgroup per CU walks its pairs with the SAME body, a barrier between pairs)
+    for (int bh = blockIdx.x;; bh += gridDim.x) {
+    // the thread index passes through an empty asm in every round: nothing derived from it is loop-invariant for hipcc, which would
+    // otherwise hoist the ~60 lane-constant LDS bases and offsets of the body out of the walk and keep them live across it
+    // (256 VGPRs + 51 spills, two scratch reloads in every query tile -- what made the persistent forms of round 3 1.7x slower)
+    int t = threadIdx.x;
+    if (PERSIST) asm volatile("" : "+v"(t));
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);          // scalar: tile picks, LDS-DMA destinations, output-tile ids stay in SGPRs
+    const int b = bh / p.H, h = bh - b * p.H;
+    const __bf16* seq = p.qkv + (size_t)b * T * ld;
+    const __bf16* dob = p.dout + (size_t)b * T * D + h * HD;
+    const __bf16* ob = p.o + (size_t)b * T * D + h * HD;
     FZ_STAMP(0);
     // ---- stage Q, dO (1-KiB pieces of 8 rows; rows past L repeat row L) and K (64-row tiles, `row & 7` swizzle: frag_tr)
     {
@@ -560,6 +567,9 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
         }
     }
     FZ_STAMP(6);
+    if (!PERSIST || bh + (int)gridDim.x >= p.B * p.H) break;
+    __syncthreads();                                   // the slabs were the images: nobody stages the next pair over a slab still being read
+    }
 }
 
 // (Two wave groups HALF a query tile apart -- waves w and w + NT / 2 share a SIMD and run every phase of a tile at the same time;
@@ -608,19 +618,14 @@ struct KsLds {
     static_assert(2 * IMG >= 8 * 32 * FZ_SLAB_STRIDE, "epilogue slabs must fit the Q / dO images");
 };
 
-template <int NT>
+template <int NT, bool PERSIST = false>
 __global__ __launch_bounds__(512, 1) void attn_bwd_dkdv_ks_kernel(AttnParams p) {
     using LY = KsLds<NT>;
     constexpr int L = LY::L, ROWS = LY::ROWS, NW = 8, KH = NT / 8;
     static_assert(NT % 8 == 0, "whole key halves of 8 waves");
     __shared__ __attribute__((aligned(1024))) char lds[LY::TOTAL];
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int kh = blockIdx.x % KH, bh = blockIdx.x / KH, b = bh / p.H, h = bh - b * p.H;
     const int T = p.T, D = p.D;                       // T = L + 1
     const size_t ld = (size_t)3 * D;
-    const __bf16* seq = p.qkv + (size_t)b * T * ld;
-    const __bf16* dob = p.dout + (size_t)b * T * D + h * HD;
     const float c = p.scale * 1.4426950408889634f;
     char* qs = lds + LY::OFF_Q;
     char* dos = lds + LY::OFF_DO;
@@ -628,12 +633,22 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkdv_ks_kernel(AttnParams p) 
     float* ndel = reinterpret_cast<float*>(lds + LY::OFF_NDEL);
     float* part = reinterpret_cast<float*>(lds + LY::OFF_PART);
     float* lonekv = reinterpret_cast<float*>(lds + LY::OFF_LONE);
-    const int kk = lane & 31, hh = lane >> 5, i16 = lane & 15, g = lane >> 4;
     if (p.stagger_phases > 1 && (int)blockIdx.x < p.stagger_n) {       // first round in shifted groups (see attn_bwd_fused_kernel)
         const int ph = blockIdx.x % p.stagger_phases;
         const unsigned long long t0 = __builtin_readcyclecounter();
         while (__builtin_readcyclecounter() - t0 < (unsigned long long)ph * p.stagger_cycles) __builtin_amdgcn_s_sleep(16);
     }
+    // PERSIST: one workgroup per CU walks the (pair, key half) work items; the thread index goes through an empty asm per round so
+    // that nothing derived from it is hoisted out of the walk (attn_bwd_fused_kernel)
+    for (int wid = blockIdx.x;; wid += gridDim.x) {
+    int t = threadIdx.x;
+    if (PERSIST) asm volatile("" : "+v"(t));
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int kh = wid % KH, bh = wid / KH, b = bh / p.H, h = bh - b * p.H;
+    const __bf16* seq = p.qkv + (size_t)b * T * ld;
+    const __bf16* dob = p.dout + (size_t)b * T * D + h * HD;
+    const int kk = lane & 31, hh = lane >> 5, i16 = lane & 15, g = lane >> 4;
 
     // ---- stage Q, dO (1-KiB pieces of 8 rows; rows L + 1 .. L + 7 repeat row L, the rest of the last tile is zero)
     {
@@ -866,7 +881,11 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dkdv_ks_kernel(AttnParams p) 
             }
         }
     }
+    if (!PERSIST || wid + (int)gridDim.x >= p.B * p.H * KH) break;
+    __syncthreads();                                   // the slabs were the images
+    }
 }
+
 
 // (The same kernel with the load phase PIPELINED was built and verified in round 3 -- the Q / dO images in four chunks of four query
 // tiles, each chunk its own __shared__ array, all LDS-DMAs issued up front in chunk order, the loop started behind chunk 0 and passing

@@ -507,6 +507,35 @@ def test_attention_backward_fused_kernels_against_the_two_kernel_path(B, T, H):
     assert (last <= tol.view(B, T, 3 * D)[:, T - 1]).all()
 
 
+@pytest.mark.parametrize('B,H', [(43, 6), (25, 12), (300, 1), (23, 12)])
+def test_attention_backward_persistent_walk_equals_a_workgroup_per_pair(B, H):
+    """T = 257 with more (batch, head) pairs than CUs: one workgroup per CU WALKS its pairs (the default).  Bit for bit what a
+    workgroup per pair computes (variant bit 7), pair counts that are not a multiple of the CU count (some workgroups walk one pair
+    more than others; 23 x 12 = 276: a second round of 20), and the usual error against fp32 autograd on a slice."""
+    from p4p_amd import _lib
+    lib = _lib.lib()
+    T, D = 257, 64 * H
+    g = torch.Generator().manual_seed(B * 100 + H)
+    qkv = (torch.randn(B * T, 3 * D, generator=g) * 1.5).to(torch.bfloat16).to(DEV)
+    dout = torch.randn(B * T, D, generator=g).to(torch.bfloat16).to(DEV)
+    out, lse = ops.attention_fwd(qkv, B, T, H)
+    assert B * H > _lib.call_int('p4p_device_cu_count')
+    try:
+        lib.p4p_set_attention_variant(128)
+        per_pair, per_pair_cs = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
+        per_pair, per_pair_cs = per_pair.clone(), per_pair_cs.clone()
+    finally:
+        lib.p4p_set_attention_variant(0)
+    walk, walk_cs = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
+    assert torch.equal(walk, per_pair) and torch.equal(walk_cs, per_pair_cs)
+    nb = min(B, 3)                                       # reference on the first and the last sequences (the walk's last round)
+    for sl in (slice(0, nb * T), slice((B - nb) * T, B * T)):
+        qr = qkv[sl].float().requires_grad_(True)
+        _attn_ref(qr, nb, T, H).backward(dout[sl].float())
+        sc = max(qr.grad.abs().max().item(), 1.0)
+        assert (walk[sl].float() - qr.grad).abs().max().item() <= 3e-2 * sc
+
+
 @pytest.mark.parametrize('B,T,runs', [(128, 513, 40), (256, 257, 20), (8, 2049, 10)])
 def test_attention_backward_is_bitwise_reproducible_under_load(B, T, runs):
     """A chip-filling launch repeated many times gives the same bits every time.  Regression for a barrier in the streaming

@@ -28,9 +28,13 @@ for B, T, H in [(2, 65, 3), (1, 129, 1), (3, 129, 2), (2, 257, 3), (5, 257, 12)]
     lib.p4p_set_attention_variant(8)
     old, old_cs = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
     old, old_cs = old.clone(), old_cs.clone()
+    lib.p4p_set_attention_variant(128)               # a workgroup per pair (the default walks the pairs: one workgroup per CU)
+    per, per_cs = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
+    per, per_cs = per.clone(), per_cs.clone()
     lib.p4p_set_attention_variant(0)
     new, new_cs = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
     torch.cuda.synchronize()
+    print('workgroup per pair == persistent walk, bit for bit:', torch.equal(per, new), torch.equal(per_cs, new_cs), flush=True)
     ref = ref_grad(qkv, dout, B, T, H)
     sc = max(ref.abs().max().item(), 1.0)
     e_old, e_new = (old.float() - ref).abs().max().item() / sc, (new.float() - ref).abs().max().item() / sc
@@ -64,11 +68,11 @@ def timeit(f, n=20):
 
 
 for rnd in range(3):
-    for v, name in ((8, 'two-kernel'), (0, 'fused')):
+    for v, name in ((8, 'two-kernel'), (128, 'fused, a workgroup per pair'), (0, 'fused, persistent walk'), (32, 'persistent, no shift')):
         lib.p4p_set_attention_variant(v)
         a = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, B, T, H))
         b = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True))
-        print(f'round {rnd} {name:16s}: bwd {a:7.1f} us   with colsum {b:7.1f} us', flush=True)
+        print(f'round {rnd} {name:24s}: bwd {a:7.1f} us   with colsum {b:7.1f} us', flush=True)
 lib.p4p_set_attention_variant(0)
 ref = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
 ref = (ref[0].clone(), ref[1].clone())

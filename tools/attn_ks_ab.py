@@ -61,11 +61,11 @@ def timeit(f, n=10):
 
 
 for rnd in range(3):
-    for v, name in ((64, 'streaming dK/dV'), (0, 'key-stationary dK/dV'), (32, 'the same, no shift')):
+    for v, name in ((64, 'streaming dK/dV'), (128, 'key-stationary, a workgroup per item'), (0, 'key-stationary, persistent walk'), (32, 'persistent, no shift')):
         lib.p4p_set_attention_variant(v)
         a = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, B, T, H))
         b = timeit(lambda: ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True))
-        print(f'round {rnd} {name:24s}: bwd {a:7.1f} us   with colsum {b:7.1f} us', flush=True)
+        print(f'round {rnd} {name:36s}: bwd {a:7.1f} us   with colsum {b:7.1f} us', flush=True)
 lib.p4p_set_attention_variant(0)
 ref = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
 ref = (ref[0].clone(), ref[1].clone())
