@@ -570,6 +570,11 @@ __global__ __launch_bounds__(NT * 64, 1) void attn_bwd_fused_kernel(AttnParams p
     if (!PERSIST || bh + (int)gridDim.x >= p.B * p.H) break;
     __syncthreads();                                   // the slabs were the images: nobody stages the next pair over a slab still being read
     }
+    // (On top of the walk, the NEXT pair's K image was prefetched by LDS-DMA into a buffer of its own -- an array of its own, raw
+    // `s_waitcnt lgkmcnt(0); s_barrier` in the query-tile loop so that nothing waits for it -- issued once the K fragments are in
+    // registers: 230 VGPRs, no wait in the loop, bit-identical, and 283-288 us against 283 us without it.  A fifth of the load
+    // phase's bytes moved under the loop does not shorten the phase; the rest cannot follow -- Q' / dO' could refill the tiles the
+    // loop is done with, but V' / O' (66 KB) have no LDS left at 144 KB.  Not kept.)
 }
 
 // (Two wave groups HALF a query tile apart -- waves w and w + NT / 2 share a SIMD and run every phase of a tile at the same time;
