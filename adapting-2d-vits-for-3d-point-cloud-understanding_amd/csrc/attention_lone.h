@@ -226,6 +226,11 @@ __global__ __launch_bounds__(LONE_NW * 64, 2) void attn_fwd_lone_res_kernel(Attn
 // second LDS buffer filled by LDS-DMA, which needs inline-asm fragment reads first (hipcc parks every builtin ds_read behind
 // vmcnt(0) while a DMA is outstanding): DESIGN.md section 9.)
 
+// (The walk of attn_bwd_fused_kernel -- a fixed number of workgroups, here two per CU, each taking every 512th (b,h) pair with the same
+// body -- was measured on this kernel in round 3: 112-115 us against 99-102 us.  With two workgroups per CU the hardware's
+// dispatch lets them drift apart, so that one loads while the other computes; the walk starts both at the same time and keeps them
+// in step.  Not kept.)
+
 // (A FUSED backward for these shapes -- one workgroup per (b,h): Q, dO, K and a dS^T tile buffer in LDS (138 KB), dK^T / dV^T
 // accumulators in registers for the whole kernel, dS crossing LDS once for dQ, the last row's three gradient rows as
 // matrix-vector MFMAs -- was built in round 2 and verified against fp32 autograd (same errors as the two-kernel path).
