@@ -229,7 +229,12 @@ __global__ __launch_bounds__(LONE_NW * 64, 2) void attn_fwd_lone_res_kernel(Attn
 // (The walk of attn_bwd_fused_kernel -- a fixed number of workgroups, here two per CU, each taking every 512th (b,h) pair with the same
 // body -- was measured on this kernel in round 3: 112-115 us against 99-102 us.  With two workgroups per CU the hardware's
 // dispatch lets them drift apart, so that one loads while the other computes; the walk starts both at the same time and keeps them
-// in step.  Not kept.)
+// in step.  Not kept.  Nor was the full form of it: ONE workgroup of 8 waves per CU, K | V in two 64-KB buffers (two __shared__
+// arrays), the LDS-DMAs of pair n + 1 and its query / last-row fragments in flight while pair n is computed, the body written out
+// for both buffers, a raw barrier in front of the last row's combine -- bit-identical, no wait for the DMAs anywhere in the body
+// (once frag_tr's second read kept its alias-scope info: attention.hip), 248 VGPRs, and 118-125 us against 100-112 us: the two
+// barriers per pair and the last-row tail (4 of 8 waves, then one) are paid by the whole CU, where two independent workgroups
+// fill each other's gaps.)
 
 // (A FUSED backward for these shapes -- one workgroup per (b,h): Q, dO, K and a dS^T tile buffer in LDS (138 KB), dK^T / dV^T
 // accumulators in registers for the whole kernel, dS crossing LDS once for dQ, the last row's three gradient rows as
