@@ -98,18 +98,18 @@ __device__ __forceinline__ bf16x8 frag_tr(const char* tile, int s, int cb, int l
     const int row = 32 * s + 4 * g + (i >> 2);
     const int p = i & 3;
     const int lchunk = 2 * cb + (p >> 1);
-    // Both addresses as ONE offset from the tile (row + 16 has the same `row & 7`, and bit 11 of the first offset is clear).  Not
-    // cosmetic: hipcc turned the second address into `first + 2048`, a pointer derived from a derived pointer, and its LDS lowering
-    // (whose walk over a pointer's users is depth-limited) then no longer found the array behind it: the read carried no
-    // alias-scope info, and a read without it waits for EVERY LDS-DMA in flight (vmcnt(0)), whatever array the DMA writes
-    // (MIR before si-insert-waitcnts: 144 of 288 transposed reads without `!alias.scope`; with this form none).  With it, a kernel
-    // whose staging buffers are separate __shared__ arrays overlaps the DMA of the next tile with the math of this one -- measured
-    // on attn_fwd_q_kernel (two arrays, loop written out for both): no vmcnt wait left in the loop, and T = 513 353-356 -> 354-362 us,
-    // T = 2049 370-372 -> 363 us: the workgroups sharing a CU had been hiding the staging already (and 126 -> 144 VGPRs cost one of
-    // four).  The loop stays as it was; the address form stays.
-    const int off0 = row * 128 + ((lchunk ^ (row & 7)) << 4) + (p & 1) * 8;
-    const char* a0 = tile + off0;
-    const char* a1 = tile + (off0 | (16 * 128));
+    // (Round 3, measured and NOT adopted: both addresses as ONE offset from the tile, `tile + (off | 2048)`.  As written here hipcc
+    // turns the second address into `first + 2048` -- an immediate on the same address register, free -- but a pointer derived from a
+    // derived pointer, which its LDS lowering (depth-limited walk over a pointer's users) no longer traces to its array: that read
+    // carries no alias-scope info, and a read without it waits for EVERY LDS-DMA in flight (vmcnt(0)), whatever array the DMA
+    // writes (MIR before si-insert-waitcnts: 144 of 288 transposed reads of a kernel without `!alias.scope`; with the one-offset
+    // form none).  That is the mechanism behind "hipcc drains vmcnt(0) in front of ds_reads while a DMA is outstanding".  The
+    // one-offset form costs a v_or and an address register per fragment, though: attn_fwd_q_kernel<2> went from 126 VGPRs to
+    // more than 128, T = 513 forward 343-349 -> 373-376 us (same box).  The kernels here keep their staging in ONE array anyway
+    // (a read of it must wait for a DMA into it); a kernel with separate arrays per buffer needs the one-offset form in ITS reads.)
+    const char* a0 = tile + row * 128 + ((lchunk ^ (row & 7)) << 4) + (p & 1) * 8;
+    const int row1 = row + 16;
+    const char* a1 = tile + row1 * 128 + ((lchunk ^ (row1 & 7)) << 4) + (p & 1) * 8;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a1));
     typedef __attribute__((ext_vector_type(8))) short s16x8;

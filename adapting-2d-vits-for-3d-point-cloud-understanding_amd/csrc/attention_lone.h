@@ -232,7 +232,7 @@ __global__ __launch_bounds__(LONE_NW * 64, 2) void attn_fwd_lone_res_kernel(Attn
 // in step.  Not kept.  Nor was the full form of it: ONE workgroup of 8 waves per CU, K | V in two 64-KB buffers (two __shared__
 // arrays), the LDS-DMAs of pair n + 1 and its query / last-row fragments in flight while pair n is computed, the body written out
 // for both buffers, a raw barrier in front of the last row's combine -- bit-identical, no wait for the DMAs anywhere in the body
-// (once frag_tr's second read kept its alias-scope info: attention.hip), 248 VGPRs, and 118-125 us against 100-112 us: the two
+// (with frag_tr's reads in the one-offset form that keeps their alias-scope info: note in attention.hip), 248 VGPRs, and 118-125 us against 100-112 us: the two
 // barriers per pair and the last-row tail (4 of 8 waves, then one) are paid by the whole CU, where two independent workgroups
 // fill each other's gaps.)
 
