@@ -18,16 +18,24 @@ class P4PError(RuntimeError):
     pass
 
 
+def _header_text():
+    try:
+        return open(HEADER_PATH).read()
+    except OSError as e:
+        raise P4PError(f'{HEADER_PATH} cannot be read ({e}): the package is deployed without include/p4p_hip.h, whose '
+                       'P4P_ABI_VERSION the loader compares with the library') from e
+
+
 def declared_symbols():
     """Entry points named in include/p4p_hip.h (used by the CPU test that checks the exports)."""
-    text = open(HEADER_PATH).read()
+    text = _header_text()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
     return sorted(set(re.findall(r'\b(p4p_[a-z0-9_]+)\s*\(', text)))
 
 
 def header_abi_version():
     """P4P_ABI_VERSION of include/p4p_hip.h: the ABI this Python package was written against."""
-    m = re.search(r'#define\s+P4P_ABI_VERSION\s+(\d+)', open(HEADER_PATH).read())
+    m = re.search(r'#define\s+P4P_ABI_VERSION\s+(\d+)', _header_text())
     if m is None:
         raise P4PError(f'{HEADER_PATH}: P4P_ABI_VERSION not found')
     return int(m.group(1))

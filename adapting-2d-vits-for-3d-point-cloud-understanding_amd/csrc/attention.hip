@@ -1208,7 +1208,9 @@ __global__ __launch_bounds__(RES_DKDV_NW * 64, 2) void attn_bwd_dkdv_res_kernel(
 #include "attention_fused.h"
 
 // experiment switch for tools/attn_ab.py (in-process A/B, default 0 = automatic): bit 0 = no resident forward / dQ,
-// bit 1 = no resident dK/dV, bit 2 = no two-pass (64 n + 1) forward, bit 3 = no fused backward, bit 5 = no start shift of the fused backward, bit 6 = no key-stationary dK/dV at T = 513.  Nothing in the product path sets it.
+// bit 1 = no resident dK/dV, bit 2 = no two-pass (64 n + 1) forward, bit 3 = no fused backward, bit 5 = no start shift of the
+// fused / key-stationary backward, bit 6 = no key-stationary dK/dV at T = 513, bit 7 = a workgroup per pair instead of the walk,
+// bits 8-9 = start-shift phases - 1 and bits 10.. = shift in 1024-cycle units (sweeps).  Nothing in the product path sets it.
 static int g_attn_variant = 0;
 extern "C" int p4p_set_attention_variant(int v) { int o = g_attn_variant; g_attn_variant = v; return o; }
 
@@ -1285,12 +1287,8 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
     p.qkv = (const __bf16*)qkv; p.o = (const __bf16*)o; p.dout = (const __bf16*)dout; p.out = (__bf16*)dqkv;
     p.lse2 = (float*)lse2; p.delta = delta; p.colsum = colsum_partial; p.B = B; p.T = T; p.H = H; p.D = D; p.scale = scale;
     if (attn_fused(T)) {                                 // T = 32 NT + 1 <= 257: one kernel, attention_fused.h
-        static int ncu = 0;
-        if (!ncu) {
-            int dev = 0;
-            P4P_HIP(hipGetDevice(&dev));
-            P4P_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        }
+        const int pg = p4p_persistent_grid();            // CUs of the current device - p4p_set_reserved_cus(); 0: no walking kernels
+        const int ncu = pg > 0 ? pg : 256;
         const dim3 grid(B * H);
         p.stagger_n = ncu; p.stagger_phases = 3; p.stagger_cycles = 10 * 1024;      // attention_fused.h: start-time shift of the first round
         if (g_attn_variant & 32) p.stagger_phases = 1;   // bit 5: no shift
@@ -1305,7 +1303,7 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
                 // between pairs; same box, B = 256, H = 12: 284-288 us against 304-310 us for a workgroup per pair, results
                 // bit-identical) -- no dispatch between pairs, and the start-time shift of the first round stays what it was set to.
                 // Bit 7 of the variant: a workgroup per pair.
-                if (!(g_attn_variant & 128) && B * H > ncu)
+                if (!(g_attn_variant & 128) && pg > 0 && B * H > ncu)
                     hipLaunchKernelGGL((attn_bwd_fused_kernel<8, true>), dim3(ncu), dim3(8 * 64), 0, st, p);
                 else hipLaunchKernelGGL(attn_bwd_fused_kernel<8>, grid, dim3(8 * 64), 0, st, p);
                 break;
@@ -1323,18 +1321,14 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
     }
     dim3 grid = attn_grid(B, T, H);
     if (T == 513 && !(g_attn_variant & 64)) {            // streaming dQ (+ delta), then key-stationary dK / dV with Q, dO resident: attention_fused.h
-        static int ncu = 0;
-        if (!ncu) {
-            int dev = 0;
-            P4P_HIP(hipGetDevice(&dev));
-            P4P_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        }
+        const int pg = p4p_persistent_grid();
+        const int ncu = pg > 0 ? pg : 256;
         p.stagger_n = ncu; p.stagger_phases = 3; p.stagger_cycles = 12 * 1024;
         if (g_attn_variant & 32) p.stagger_phases = 1;
         if (g_attn_variant >> 8) { p.stagger_phases = ((g_attn_variant >> 8) & 3) + 1; p.stagger_cycles = (g_attn_variant >> 10) * 1024; }
         hipLaunchKernelGGL(attn_bwd_dq_q_kernel<2>, dim3((unsigned)(ceil_div((long long)B * H, 8) * 8 * ceil_div(T, 128))), dim3(ATT_THREADS), 0, st, p);
         P4P_LAUNCH_CHECK();
-        if (!(g_attn_variant & 128) && B * H * 2 > ncu)   // one workgroup per CU walks its work items (bit 7: a workgroup per item)
+        if (!(g_attn_variant & 128) && pg > 0 && B * H * 2 > ncu)   // one workgroup per CU walks its work items (bit 7: a workgroup per item)
             hipLaunchKernelGGL((attn_bwd_dkdv_ks_kernel<16, true>), dim3(ncu), dim3(512), 0, st, p);
         else hipLaunchKernelGGL(attn_bwd_dkdv_ks_kernel<16>, dim3(B * H * 2), dim3(512), 0, st, p);
         P4P_LAUNCH_CHECK();

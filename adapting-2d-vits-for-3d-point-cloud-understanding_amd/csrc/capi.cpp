@@ -79,6 +79,54 @@ extern "C" int p4p_stream_destroy(void* stream) {
     P4P_HIP(hipStreamDestroy((hipStream_t)stream));
     return 0;
 }
+// ---- persistent kernels and the compute units other work needs -----------------------------------------------------
+// The persistent tile loop of gemm_tn4p.h and the walking attention backward kernels (attention_fused.h) launch ONE workgroup
+// per CU, each with a static share of the work and all of the CU's LDS.  A concurrent kernel that holds r CUs for a long time
+// (RCCL's all-reduce workgroups during a data-parallel backward) makes r of those workgroups start only when others have
+// finished -- with their whole share still to do, the launch takes up to twice as long.  p4p_set_reserved_cus(r):
+//   r = 0 (default, world size 1): grid = all CUs;   r > 0: grid = CUs - r (rounded up to a multiple of 8 so that a workgroup's
+//   tiles stay on one XCD), the tile loops stride by the grid size;   r < 0: no persistent kernels at all (a workgroup per tile /
+//   pair: the hardware dispatcher balances whatever CUs are free).  ddp.build_reducer sets it when world > 1.
+static int g_reserved_cus = 0;
+extern "C" int p4p_set_reserved_cus(int r) {
+    int o = g_reserved_cus;
+    g_reserved_cus = r < 0 ? -1 : (r + 7) / 8 * 8;
+    return o;
+}
+int p4p_persistent_grid(void) {              // workgroups of a persistent launch on the current device; 0: do not launch persistent kernels
+    static int ncu[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (!ncu[dev] && hipDeviceGetAttribute(&ncu[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (g_reserved_cus < 0) return 0;
+    const int g = ncu[dev] - g_reserved_cus;
+    return g >= 64 ? g : 64;                 // never fewer than a quarter of an MI355X
+}
+extern "C" int p4p_persistent_grid_size(void) { return p4p_persistent_grid(); }
+
+// A stand-in for a long-lived foreign kernel (tools/contention_rehearsal.py): `workgroups` single-wave workgroups that each hold
+// `lds_bytes` of LDS (> 80 KiB: one per CU, and no 160-KiB workgroup of ours fits beside it) and sleep until `microseconds` of
+// s_memrealtime (100 MHz) have passed -- a bounded wait every wave reaches the end of, whatever else happens.
+__global__ void occupy_cus_kernel(long long ticks, int* sink) {
+    extern __shared__ __attribute__((aligned(16))) char occ_lds[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    occ_lds[threadIdx.x] = (char)threadIdx.x;
+    while ((long long)(__builtin_amdgcn_s_memrealtime() - t0) < ticks) __builtin_amdgcn_s_sleep(64);
+    if (sink && occ_lds[threadIdx.x] == 77 && ticks < 0) *sink = 1;          // keeps the LDS store alive; never true
+}
+extern "C" int p4p_debug_occupy_cus(int workgroups, int lds_bytes, long long microseconds, void* stream) {
+    P4P_CHECK(workgroups >= 1 && workgroups <= 256 && lds_bytes >= 64 && lds_bytes <= 160 * 1024 && microseconds >= 1 &&
+              microseconds <= 5000000, "p4p_debug_occupy_cus: bad arguments (workgroups=%d, lds=%d, us=%lld)", workgroups, lds_bytes, microseconds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        P4P_HIP(hipFuncSetAttribute((const void*)occupy_cus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(occupy_cus_kernel, dim3(workgroups), dim3(64), lds_bytes, (hipStream_t)stream, microseconds * 100, (int*)nullptr);
+    P4P_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int p4p_device_cu_count(void) {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;

@@ -125,6 +125,9 @@ __device__ __forceinline__ float sqdist3(float x, float y, float z, float cx, fl
 
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// persistent launches (capi.cpp): workgroups = CUs of the current device - p4p_set_reserved_cus(); 0 = no persistent kernels
+int p4p_persistent_grid(void);
+
 // launch profiler (capi.cpp): brackets one kernel launch with HIP events when enabled for `kind`
 bool p4p_prof_begin(int kind, double flops, hipStream_t st);
 void p4p_prof_end(hipStream_t st);

@@ -130,7 +130,10 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
         // row tile(s) off and run them with the 128x128 configuration (many small workgroups, one short round).
         const bool row_remap = EPI == EPI_F32_RESID && p.group > 1;      // token-stream output rows: no peeling / split-K
         if ((v == 3 || v == 4 || v == 5 || v == 7 || v == 8 || v == 10) && !row_remap) {
-            const int bn = (v == 3 || v == 7 || v == 8 || v == 10) ? 256 : T3_BN, slots = (v == 3 || v == 7 || v == 8 || v == 10) ? 256 : 512;
+            // slots = workgroups resident at once: 256 CUs (two 256 x 128 workgroups each), or what p4p_set_reserved_cus() leaves
+            // of them for the staggered / persistent 256 x 256 kernels (capi.cpp; 256 at world size 1)
+            const int pgrid = v == 10 ? p4p_persistent_grid() : 0;
+            const int bn = (v == 3 || v == 7 || v == 8 || v == 10) ? 256 : T3_BN, slots = (v == 3 || v == 7 || v == 8 || v == 10) ? (pgrid > 0 ? pgrid : 256) : 512;
             const int tiles_n = ceil_div(p.N, bn), tiles_m = ceil_div(p.M, 256);       // the last panel may be ragged: it is peeled first
             const long long total = (long long)tiles_m * tiles_n;
             const long long rounds = total / slots, rem = total % slots;
@@ -202,10 +205,11 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
                 int tiles = ceil_div(p.M, 256) * (p.N / 256);
                 // several tiles per CU and an even number (>= 4) of K-tiles: the persistent loop of gemm_tn4p.h hides the per-tile
                 // dispatch + pipeline-fill latency behind the previous tile's epilogue
-                if ((g_tn4_persistent & 1) && tiles >= 512 && p.K % 128 == 0 && p.K >= 256 && p.K <= 2304) {
+                const int pg = p4p_persistent_grid();       // CUs - reserved (capi.cpp); 0: a workgroup per tile
+                if ((g_tn4_persistent & 1) && pg > 0 && tiles >= 2 * pg && p.K % 128 == 0 && p.K >= 256 && p.K <= 2304) {
                     GemmParams pb = p;
                     pb.band = (g_tn4_persistent & 2) ? 0 : 1;
-                    hipLaunchKernelGGL((gemm_tn4p_kernel<EPI>), dim3(256), dim3(512), 0, st, pb);
+                    hipLaunchKernelGGL((gemm_tn4p_kernel<EPI>), dim3(pg), dim3(512), 0, st, pb);
                     P4P_LAUNCH_CHECK();
                     return 0;
                 }

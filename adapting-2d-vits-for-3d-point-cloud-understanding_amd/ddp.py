@@ -25,6 +25,7 @@ xGMI is point-to-point (7 links per GPU): a ViT-B gradient set is 345 MB fp32; t
 backward compute; ``bucket_mb`` merges consecutive blocks into larger buckets (to be tuned against the measured RCCL bus
 bandwidth on an 8-GPU node: bench.py prints per-rank step times and the exposed all-reduce wait).
 """
+import os
 from typing import Iterable, List, Optional
 
 import torch
@@ -32,12 +33,21 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, bucket_params: List[List[torch.nn.Parameter]], process_group=None, blocks_per_bucket=None):
+    def __init__(self, bucket_params: List[List[torch.nn.Parameter]], process_group=None, blocks_per_bucket=None,
+                 outside: Optional[Iterable[torch.nn.Parameter]] = None, force_collectives: bool = False):
         """bucket_params[i] = parameters of bucket i, in the order buckets become ready; the last bucket is the tail reduced
-        by finish().  blocks_per_bucket[i] (optional) = how many block_done calls complete bucket i (default 1)."""
+        by finish().  blocks_per_bucket[i] (optional) = how many block_done calls complete bucket i (default 1).
+        outside: the model's parameters that are in NO bucket (frozen or never used at build time); finish() refuses a step in
+        which one of them turned trainable or received a gradient (it would never be all-reduced).
+        force_collectives: launch the all-reduces at world size 1 too (a process group must exist) -- the single-GPU
+        rehearsal of the RCCL stream hand-off, tests/test_gpu_ddp.py."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.grad_scale = 1.0 / self.world
+        self.force_collectives = bool(force_collectives)
+        if self.force_collectives and not dist.is_initialized():
+            raise RuntimeError('GradReducer(force_collectives=True) needs an initialised process group')
+        self.collectives_launched = 0      # all-reduces handed to the backend so far (diagnostic; bench.py prints it)
         self.buckets = []
         self._regions = {}                 # id(first parameter of a block) -> [bucket, start, end, written this step]
         params = [p for b in bucket_params for p in b]
@@ -59,7 +69,10 @@ class GradReducer:
         self._handles = []
         self._launched = set()
         self._trainable = [(p, p.requires_grad) for p in params]
+        inside = {id(p) for p in params}
+        self._outside = [p for p in (outside or []) if id(p) not in inside]
         self._stale_zeroed = 0             # regions finish() had to zero (a block whose backward did not write): diagnostic
+        self.reserved_cus = None           # what build_reducer told the library to leave to RCCL (None: untouched)
 
     def register_block(self, params: Iterable[torch.nn.Parameter]):
         """Declare one block (a run of consecutive parameters of one bucket that the backward writes as a unit): finish()
@@ -72,11 +85,18 @@ class GradReducer:
 
     def check_trainable(self):
         """The bucket layout is fixed at construction: a requires_grad flag flipped afterwards (staged unfreezing) would leave
-        a block without its per-step write (stale sums) or a gradient outside the buffer.  Rebuild the reducer instead."""
+        a block without its per-step write (stale sums) or a gradient outside the buffer.  Rebuild the reducer instead.
+        Both directions are refused: trainable -> frozen for a bucketed parameter, and frozen -> trainable (or a gradient
+        that appeared) for a parameter that was left out of the buckets -- its gradient would stay local to the rank and the
+        ranks would diverge without an error."""
         for p, was in self._trainable:
             if p.requires_grad != was:
                 raise RuntimeError('GradReducer: requires_grad of a bucketed parameter changed after build_reducer(); '
                                    'build a new reducer for the new set of trainable parameters')
+        for p in self._outside:
+            if p.requires_grad and p.grad is not None:
+                raise RuntimeError('GradReducer: a parameter outside the buckets (frozen or unused at build_reducer()) received a '
+                                   'gradient: it would not be all-reduced; build a new reducer after changing what is trainable')
 
     # -- called from inside backward ---------------------------------------------------------
     def grad_views(self, params: Iterable[torch.nn.Parameter]):
@@ -116,9 +136,10 @@ class GradReducer:
         return [None] * len(grads)
 
     def _launch(self, i):
-        if self.world > 1 and i not in self._launched:
+        if (self.world > 1 or self.force_collectives) and i not in self._launched:
             s, e = self.buckets[i]
             self._handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.collectives_launched += 1
         self._launched.add(i)
 
     # -- called after backward ---------------------------------------------------------------
@@ -145,6 +166,12 @@ class GradReducer:
         if average and self.world > 1:
             self.flat.mul_(self.grad_scale)
 
+    def describe(self):
+        """Bucket layout for logs / bench.py: count, bytes per bucket (in readiness order, the tail last), reserved CUs."""
+        return {'buckets': len(self.buckets), 'bucket_bytes': [(e - s) * 4 for s, e in self.buckets],
+                'total_bytes': int(self.flat.numel()) * 4, 'reserved_cus': self.reserved_cus,
+                'collectives_launched': self.collectives_launched}
+
     def zero_grad(self):
         """Only the tail bucket accumulates (autograd adds into its views); the block buckets are overwritten by the
         encoder's backward (finish() zeroes any registered block that was NOT written in a step)."""
@@ -152,10 +179,31 @@ class GradReducer:
         self.flat[s:e].zero_()
 
 
-def build_reducer(model, process_group=None, bucket_mb=None) -> GradReducer:
+def reserve_cus_for_collectives(world, reserved_cus=None):
+    """RCCL's all-reduce workgroups are long-lived and cannot share a CU with this library's one-workgroup-per-CU persistent
+    kernels (short-K GEMM tile loop, walking attention backward: every byte of LDS): a persistent workgroup that is dispatched
+    late still has its whole static share to do, so such a launch can take up to twice as long while an all-reduce is in flight.
+    At world > 1 those kernels therefore do not run persistently by default (a workgroup per tile / pair, balanced by the
+    hardware dispatcher over whatever CUs are free: +0.6 ms per 52-ms step on one GPU, tools/contention_rehearsal.py);
+    ``reserved_cus`` = r >= 0 (or P4P_RESERVED_CUS=r) keeps them persistent on CUs - r workgroups instead, the better choice once
+    the CU count RCCL holds has been measured on the node.  Returns the value set, None if untouched."""
+    if reserved_cus is None and 'P4P_RESERVED_CUS' in os.environ:
+        reserved_cus = int(os.environ['P4P_RESERVED_CUS'])
+    if reserved_cus is None:
+        if world <= 1:
+            return None
+        reserved_cus = -1
+    from . import ops
+    ops.set_reserved_cus(reserved_cus)
+    return reserved_cus
+
+
+def build_reducer(model, process_group=None, bucket_mb=None, force_collectives=False, reserved_cus=None) -> GradReducer:
     """Buckets for a pix4point.Pix4Point: encoder blocks last-to-first (consecutive blocks merged until a bucket holds
     at least ``bucket_mb`` MB; default: one block per bucket), then every other parameter that can receive a gradient.
-    Installs itself as the encoder's grad sink."""
+    Installs itself as the encoder's grad sink.  Every parameter of the model that ends up in no bucket (frozen blocks, the
+    never-used timm parameters of quirk 8) is remembered: GradReducer.check_trainable refuses a step in which one of them
+    received a gradient (staged unfreezing needs a new reducer)."""
     pv = model.model
     from .functional import block_params
     blocks = list(pv.vit_blocks)
@@ -176,7 +224,9 @@ def build_reducer(model, process_group=None, bucket_mb=None) -> GradReducer:
     tail = [p for p in model.parameters() if p.requires_grad and id(p) not in seen and id(p) not in unused]
     buckets.append(tail)
     counts.append(0)
-    red = GradReducer(buckets, process_group, blocks_per_bucket=counts)
+    red = GradReducer(buckets, process_group, blocks_per_bucket=counts, outside=list(model.parameters()),
+                      force_collectives=force_collectives)
+    red.reserved_cus = reserve_cus_for_collectives(red.world, reserved_cus)
     for blk in blocks:
         bp = [p for p in block_params(blk) if p.requires_grad]
         if bp and len(bp) == 12:

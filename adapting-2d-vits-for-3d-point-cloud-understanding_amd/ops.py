@@ -581,3 +581,16 @@ def augment(points, flags, affine=None, jitter=None, clip=0.05, replace_mask=Non
     L.call('p4p_augment_f32', L.ptr(points), L.ptr(out), L.ptr(flags), L.ptr(affine), L.ptr(jitter), float(clip),
            L.ptr(replace_mask), L.ptr(replace_u), L.ptr(replace_g), L.ptr(dropout_mask), B, N, _stream())
     return out
+
+
+def set_reserved_cus(r):
+    """Compute units the persistent kernels (short-K GEMM tile loop, walking attention backward) leave to a concurrent
+    long-lived kernel -- RCCL's all-reduce workgroups under data parallelism.  0: all CUs; r > 0: grids of CUs - r
+    (multiples of 8), results bit-identical; r < 0: a workgroup per tile / pair.  Returns the previous value."""
+    return L.call_int('p4p_set_reserved_cus', int(r))
+
+
+def persistent_grid_size():
+    """Workgroups a persistent launch takes on the current device now (0: no persistent kernels are launched)."""
+    return L.call_int('p4p_persistent_grid_size')
+

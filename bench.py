@@ -187,7 +187,20 @@ def live_pmc_traffic(kernel_substr, timeout_s=150):
                    sys.executable, os.path.abspath(__file__), '--steps', '1', '--warmup', '1', '--no-cpu-baseline', '--no-roofline',
                    '--no-north-star', '--no-pmc']
             env = dict(os.environ, TMPDIR='/tmp')
-            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            # own session: on a timeout the whole group goes (rocprofv3 AND the child python that owns the GPU), and is waited
+            # for, so that nothing of it runs beside a later timed section
+            proc = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, start_new_session=True)
+            try:
+                proc.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                proc.communicate()
+                return None, f'rocprofv3 --pmc {ctr} timed out after {timeout_s} s (process group killed)'
+            r = proc
             files = glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True)
             if r.returncode != 0 or not files:
                 return None, f'rocprofv3 --pmc {ctr} failed (rc {r.returncode})'
@@ -406,6 +419,9 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+LAST_ENQUEUE_S = [0.0]
+
+
 def timed_steps(stepper, batch, steps, fence, distributed, device, optim=True):
     """EXACTLY `steps` steps between two fences (barrier + device synchronize); seconds, max over ranks, and every
     rank's own time."""
@@ -413,6 +429,7 @@ def timed_steps(stepper, batch, steps, fence, distributed, device, optim=True):
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = stepper.step(*batch, optim=optim)
+    LAST_ENQUEUE_S[0] = time.perf_counter() - t0          # host time to ENQUEUE the steps (no sync): ~= elapsed means host-bound
     fence()
     elapsed = time.perf_counter() - t0
     per_rank = [elapsed]
@@ -517,11 +534,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    ddp_info = None
+    if getattr(stepper, 'reducer', None) is not None:
+        from p4p_amd import ops as _ops
+        ddp_info = dict(stepper.reducer.describe(), backend=dist.get_backend(), persistent_grid=_ops.persistent_grid_size())
+        log(f'rank {rank}: gradient buckets {ddp_info["buckets"]} ({ddp_info["total_bytes"] * 1e-6:.0f} MB in all), reserved CUs '
+            f'{ddp_info["reserved_cus"]}, persistent grid {ddp_info["persistent_grid"]}')
     log(f'rank {rank}/{world}: model built, warm-up {args.warmup} steps')
     for _ in range(args.warmup):
         stepper.step(*batch)
     elapsed, per_rank, loss_val = timed_steps(stepper, batch, args.steps, fence, distributed, device)
-    log(f'timed region: {args.steps} steps in {elapsed:.3f} s')
+    host_enqueue_ms = LAST_ENQUEUE_S[0] / args.steps * 1e3
+    log(f'timed region: {args.steps} steps in {elapsed:.3f} s (host enqueue {LAST_ENQUEUE_S[0]:.3f} s)')
     # the metric's literal "fwd+bwd" (no clip / AdamW), SURVEY.md section 8d's first figure: the same K steps again
     fb_elapsed, _, _ = timed_steps(stepper, batch, args.steps, fence, distributed, device, optim=False)
 
@@ -537,13 +561,6 @@ def main():
             roof['index_ops'] = index_ops_roofline(args.batch, args.points, args.points // 4, 16, device)
         log('instrumented roofline pass done')
     ar_wait = allreduce_exposed_ms(stepper, batch) if distributed else None
-    if rank == 0 and roof is not None and world == 1 and default_config and not args.no_pmc:
-        live, note = live_pmc_traffic('gemm_wgrad3_kernel')
-        if live is not None:
-            roof['traffic'], roof['traffic_note'] = live, note
-        else:
-            roof['traffic_note'] = (roof.get('traffic_note') or '') + f' (live collection skipped: {note})'
-        log('PMC traffic: ' + note)
 
     # ---- the point north_star states its utilisation targets at: N=2048, B=256, ViT-B/12, one GPU
     ns = None
@@ -554,6 +571,7 @@ def main():
             stepper.step(*ns_batch)
         ns_steps = 10
         ns_el, _, _ = timed_steps(stepper, ns_batch, ns_steps, fence, False, device)
+        ns_enq = LAST_ENQUEUE_S[0] / ns_steps * 1e3
         ns_fb, _, _ = timed_steps(stepper, ns_batch, 5, fence, False, device, optim=False)
         ns_roof = instrumented_roofline(stepper, ns_batch, 2, attn_dims=(nb, npts // 4 + 1, vd)) if not args.no_roofline else None
         fl = flop_per_cloud(npts, vd, vl)
@@ -561,7 +579,7 @@ def main():
         ns = {'workload': f'Pix4Point {args.vit} N={npts} k=16, batch {nb}, 1 GPU (same step as the headline line)',
               'clouds_per_sec': v, 'ms_per_step': ns_el / ns_steps * 1e3, 'steps': ns_steps,
               'algorithmic_gflop_per_cloud': fl * 1e-9, 'algorithmic_tflops': v * fl * 1e-12,
-              'mfma_frac_whole_step': v * fl * 1e-12 / PEAK_BF16_TFLOPS,
+              'mfma_frac_whole_step': v * fl * 1e-12 / PEAK_BF16_TFLOPS, 'host_enqueue_ms_per_step': ns_enq,
               'fwd_bwd_only': {'clouds_per_sec': nb * 5 / ns_fb, 'ms_per_step': ns_fb / 5 * 1e3}}
         if ns_roof:
             ns['gemm_wgrad_TFLOPs'] = ns_roof['achieved']
@@ -582,19 +600,42 @@ def main():
         a2.dim = ld_
         st2 = Stepper(a2, device, False)
         b2 = synthetic_batch(a2.batch, a2.points, a2.classes, 777, device)
-        for _ in range(2):
+        for _ in range(3):
             st2.step(*b2)
-        k_steps = 5
-        el2, _, _ = timed_steps(st2, b2, k_steps, fence, False, device)
+        k_steps = 20
+        runs = []
+        for _ in range(3):                              # three timed regions of 20 steps: the scatter between them is reported
+            el2, _, _ = timed_steps(st2, b2, k_steps, fence, False, device)
+            runs.append((el2 / k_steps * 1e3, LAST_ENQUEUE_S[0] / k_steps * 1e3))
+        runs.sort()
+        ms2, enq2 = runs[1]                             # median region
         fl2 = flop_per_cloud(a2.points, ld_, ll_)
-        v2 = a2.batch * k_steps / el2
+        v2 = a2.batch / (ms2 * 1e-3)
         n8k = {'workload': f'Pix4Point {a2.vit} (D={ld_}, {ll_} blocks, {lh_} heads) N=8192 k=16, batch {a2.batch}, 1 GPU (same step as the headline line)',
-               'clouds_per_sec': v2, 'ms_per_step': el2 / k_steps * 1e3, 'steps': k_steps,
+               'clouds_per_sec': v2, 'ms_per_step': ms2, 'steps': k_steps, 'ms_per_step_runs': [r[0] for r in runs],
+               'scatter_pct': (runs[-1][0] - runs[0][0]) / ms2 * 50.0,      # +- half of the range, in % of the median
+               'host_enqueue_ms_per_step': enq2,
                'algorithmic_gflop_per_cloud': fl2 * 1e-9, 'algorithmic_tflops': v2 * fl2 * 1e-12,
                'mfma_frac_whole_step': v2 * fl2 * 1e-12 / PEAK_BF16_TFLOPS}
+        if not args.no_roofline:
+            r2 = instrumented_roofline(st2, b2, 2, attn_dims=(a2.batch, a2.points // 4 + 1, ld_))
+            n8k['gemm_wgrad_TFLOPs'] = r2['achieved']
+            n8k['all_mfma_gemms'] = r2['all_mfma_gemms']
+            n8k['attention'] = r2['attention']
+            n8k['per_kernel'] = r2['per_kernel']
+            n8k['index_ops'] = index_ops_roofline(a2.batch, a2.points, a2.points // 4, 16, device)
         log('N=8192 ViT-L/24 point done')
         del st2, b2
         torch.cuda.empty_cache()
+    if rank == 0 and roof is not None and world == 1 and default_config and not args.no_pmc:
+        # after EVERY timed section (a child that outlives its timeout must not run beside one), with this process's model and
+        # batches freed
+        live, note = live_pmc_traffic('gemm_wgrad3_kernel')
+        if live is not None:
+            roof['traffic'], roof['traffic_note'] = live, note
+        else:
+            roof['traffic_note'] = (roof.get('traffic_note') or '') + f' (live collection skipped: {note})'
+        log('PMC traffic: ' + note)
     if distributed:
         dist.barrier()
     cpu = None
@@ -622,7 +663,10 @@ def main():
             'fwd_bwd_only': {'value': clouds / fb_elapsed, 'unit': 'point-clouds/sec',
                              'ms_per_step': fb_elapsed / args.steps * 1e3, 'steps': args.steps},
             'per_rank_ms_per_step': [t / args.steps * 1e3 for t in per_rank],
+            'host_enqueue_ms_per_step': host_enqueue_ms,      # rank 0's host time to enqueue a step; ~= ms_per_step means host-bound
         }
+        if ddp_info is not None:
+            out['ddp'] = ddp_info
         if ar_wait is not None:
             out['allreduce_exposed_ms'] = ar_wait
         if apf:

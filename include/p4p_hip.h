@@ -19,9 +19,9 @@ extern "C" {
 #endif
 
 /* Bumped on every incompatible change of a signature below (2: p4p_clip_coef gained grad_scale, p4p_apf_group gained C;
- * 3: the version check itself; 4: p4p_layernorm_bwd gained dx_in).  libp4p_hip.so is built separately from the Python package: the binding compares p4p_abi_version() with
+ * 3: the version check itself; 4: p4p_layernorm_bwd gained dx_in; 5: p4p_set_reserved_cus / p4p_persistent_grid_size).  libp4p_hip.so is built separately from the Python package: the binding compares p4p_abi_version() with
  * this constant when it loads the library and refuses a stale build. */
-#define P4P_ABI_VERSION 4
+#define P4P_ABI_VERSION 5
 int p4p_abi_version(void);
 const char* p4p_last_error(void);
 
@@ -183,7 +183,18 @@ int p4p_device_cu_count(void);
 int p4p_set_gemm_variant(int v);
 int p4p_set_wgrad_wide(int v);
 int p4p_set_gemm_persistent(int v);        /* 1 (default): short-K GEMMs with several tiles per CU run the persistent tile loop (gemm_tn4p.h); 0: one workgroup per tile; 3: persistent without the banded tile order of wide outputs */
-int p4p_set_attention_variant(int v);      /* bit 0: no resident forward / dQ, bit 1: no resident dK/dV, bit 2: no two-pass forward */
+int p4p_set_attention_variant(int v);      /* bit 0: no resident forward / dQ, bit 1: no resident dK/dV, bit 2: no two-pass (64n+1) forward, bit 3: no fused backward (T = 32n+1 <= 257), bit 5: no start-time shift of the first round of the fused / key-stationary backward, bit 6: no key-stationary dK/dV at T = 513, bit 7: a workgroup per (b,h) pair instead of the one-workgroup-per-CU walk, bits 8-9: shift phases - 1 and bits 10..: shift in 1024-cycle units (sweeps only) */
+/* ---- persistent kernels next to a concurrent long-lived kernel (the RCCL all-reduce of a data-parallel backward; the reference has no
+ * counterpart: src/train/pix4point_trainer.py:4-6 imports DistributedDataParallel and never uses it).  The persistent tile loop of the
+ * short-K GEMMs and the walking attention backward launch one workgroup per CU with a static share of the work; r CUs held by another
+ * kernel would make r of them start late with their whole share to do.  r = 0 (default): all CUs; r > 0: CUs - r workgroups (r rounded
+ * up to a multiple of 8), results bit-identical; r < 0: a workgroup per tile / pair (no persistent kernels).  Returns the previous
+ * value.  p4p_persistent_grid_size(): workgroups a persistent launch takes on the current device now (0: none are launched). */
+int p4p_set_reserved_cus(int r);
+int p4p_persistent_grid_size(void);
+/* rehearsal aid (tools/contention_rehearsal.py): `workgroups` one-wave workgroups, each holding lds_bytes of LDS (> 80 KiB: one per
+ * CU, excluding every 160-KiB workgroup of this library from that CU) for `microseconds` (bounded: 1 .. 5,000,000), on `stream`. */
+int p4p_debug_occupy_cus(int workgroups, int lds_bytes, long long microseconds, void* stream);
 
 /* ---- global feature of PointViT.forward_cls_feat (src/models/pix4point.py:260-271) ----
    fwd: out_max[B,D] = max over tokens 1..T-1 of x[B,T,D] (arg[B,D] = token index of the first maximum), out_cls[B,D] = x[:,0]

@@ -138,3 +138,33 @@ def test_block_not_written_in_a_step_is_zeroed_not_reapplied():
     blocks[0].weight.requires_grad_(False)
     with pytest.raises(RuntimeError, match='requires_grad'):
         red.finish()
+
+
+def test_parameter_unfrozen_after_build_is_refused():
+    """the staged-unfreezing direction.  A block that was frozen when the reducer was built is in no bucket; once it
+    is unfrozen its gradient lands in a plain local .grad that no all-reduce ever sees -- finish() must refuse the step."""
+    blocks = [torch.nn.Linear(4, 4) for _ in range(2)]
+    tail = torch.nn.Linear(4, 2)
+    for p in blocks[0].parameters():
+        p.requires_grad_(False)                       # frozen at build time: not bucketed
+    every = [p for m in blocks + [tail] for p in m.parameters()]
+    red = GradReducer([list(blocks[1].parameters()), list(tail.parameters())], blocks_per_bucket=[1, 0], outside=every)
+    red.register_block(list(blocks[1].parameters()))
+    x = torch.ones(3, 4)
+    tail(blocks[1](blocks[0](x))).sum().backward()
+    red.block_done(list(blocks[1].parameters()))
+    red.finish()                                      # still frozen: fine
+    assert all(p.grad is None for p in blocks[0].parameters())
+    for p in blocks[0].parameters():
+        p.requires_grad_(True)                        # staged unfreezing without a new reducer
+    red.zero_grad()
+    tail(blocks[1](blocks[0](x))).sum().backward()
+    red.block_done(list(blocks[1].parameters()))
+    with pytest.raises(RuntimeError, match='outside the buckets'):
+        red.finish()
+
+
+def test_force_collectives_needs_a_process_group():
+    lin = torch.nn.Linear(4, 4)
+    with pytest.raises(RuntimeError, match='process group'):
+        GradReducer([list(lin.parameters())], force_collectives=True)

@@ -94,6 +94,91 @@ def _worker(rank, world, port, q, bucket_mb=None):
         dist.destroy_process_group()
 
 
+def _nccl_world1_worker(port, q):
+    """RCCL itself, as far as one GPU allows: a world-size-1 `nccl` process group and a GradReducer that launches its
+    collectives anyway (force_collectives).  The 12 in-backward async all-reduces run on RCCL's stream against views of the flat
+    buffer that the weight-gradient GEMMs have just written on the compute stream, finish() waits on their handles, and the fused
+    optimizer consumes the sums with grad_scale = 1."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+        import copy
+        import p4p_amd
+        from p4p_amd import ops
+        from p4p_amd.ddp import build_reducer
+        from p4p_amd.optim import FusedAdamW
+        from oracle import pix4point_oracle as O
+        dev = 'cuda:0'
+        torch.manual_seed(3)
+        # 12 blocks of ViT width 192 (the bucket hand-off of the real depth), N = 1024 clouds so that the persistent kernels run
+        model = p4p_amd.Pix4Point(num_classes=40, embed_dim=192, pretrained_model='vit_custom_d192_l12_h3', pretrained=False).to(dev)
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        model.train()
+        twin = copy.deepcopy(model)
+        B = 64
+        pts = O.synthetic_clouds(B, 1024, seed=5).to(dev)
+        start = (torch.arange(B) * 3).to(dev)
+        labels = torch.randint(0, 40, (B,), generator=torch.Generator().manual_seed(1)).to(dev)
+        # (a) plain autograd, no reducer
+        torch.nn.functional.cross_entropy(twin(pts, start), labels).backward()
+        # (b) the reducer with real collectives; the buckets are poisoned first: every byte must come from this step
+        red = build_reducer(model, force_collectives=True, reserved_cus=0)
+        assert red.world == 1 and len(red.buckets) == 13
+        red.flat.fill_(float('nan'))
+        red.zero_grad()
+        torch.nn.functional.cross_entropy(model(pts, start), labels).backward()
+        assert red.collectives_launched == 12, red.collectives_launched        # one per block, launched from inside backward
+        red.finish(average=False)
+        assert red.collectives_launched == 13
+        for (n, p), (_, t) in zip(model.named_parameters(), twin.named_parameters()):
+            if t.grad is None:
+                assert p.grad is None, n
+            else:
+                assert torch.equal(p.grad, t.grad), n                # world 1: the sum over ranks IS the local gradient, bit for bit
+        # (c) the fused tail on the reducer's views == the fused tail on plain gradients
+        fa = FusedAdamW(model.get_param_groups(), lr=1e-3, weight_decay=5e-2)
+        fb = FusedAdamW(twin.get_param_groups(), lr=1e-3, weight_decay=5e-2)
+        fa.step(max_norm=0.05, grad_scale=red.grad_scale)
+        fb.step(max_norm=0.05)
+        for (n, p), (_, t) in zip(model.named_parameters(), twin.named_parameters()):
+            assert torch.equal(p, t), n
+        # (d) a second step reuses the views; with the persistent kernels switched off as build_reducer does at world > 1
+        ops.set_reserved_cus(-1)
+        for mdl, rd in ((model, red), (twin, None)):
+            if rd is not None:
+                rd.zero_grad()
+            else:
+                mdl.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(mdl(pts, start), labels).backward()
+            if rd is not None:
+                rd.finish(average=False)
+            ops.set_reserved_cus(0)
+        for (n, p), (_, t) in zip(model.named_parameters(), twin.named_parameters()):
+            if t.grad is not None:
+                assert torch.equal(p.grad, t.grad), n
+        q.put('ok')
+    except Exception:                                       # pragma: no cover
+        import traceback
+        q.put(traceback.format_exc())
+        raise
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_rccl_world_size_one_reducer_runs_real_collectives():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=60)
+    assert res == 'ok', res
+
+
 @pytest.mark.parametrize('bucket_mb', [None, 100.0])
 def test_two_rank_data_parallel_step_on_one_gpu(bucket_mb):
     ctx = mp.get_context('spawn')

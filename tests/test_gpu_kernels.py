@@ -536,6 +536,49 @@ def test_attention_backward_persistent_walk_equals_a_workgroup_per_pair(B, H):
         assert (walk[sl].float() - qr.grad).abs().max().item() <= 3e-2 * sc
 
 
+@pytest.mark.parametrize('r', [8, 13, 32, -1])
+def test_persistent_kernels_on_fewer_cus_are_bit_identical(r):
+    """p4p_set_reserved_cus(r): the persistent GEMM tile loop and the walking attention backward kernels launch CUs - r workgroups
+    (r rounded up to a multiple of 8; r < 0: a workgroup per tile / pair) so that a concurrent long-lived kernel -- RCCL's all-reduce
+    under data parallelism -- does not leave r of them waiting with their whole static share to do.  Same bits as with all CUs:
+    every GEMM epilogue at a shape with a ragged last panel (the peel arithmetic follows the grid size) and at the token-stream
+    shape, the fused backward at T = 257 and the key-stationary dK / dV at T = 513."""
+    from p4p_amd import _lib
+    ncu = _lib.call_int('p4p_device_cu_count')
+
+    def run_all():
+        outs = []
+        for (M, N, K) in [(257 * 256, 768, 768), (300 * 256 - 100, 2304, 768), (257 * 256, 3072, 768)]:
+            a = _int_bf16((M, K), -2, 2, 21).to(DEV)
+            w = _int_bf16((N, K), -1, 1, 22).to(DEV)
+            bias = torch.arange(N, device=DEV, dtype=torch.float32) % 5 - 2
+            resid = (torch.arange(M * N, device=DEV) % 11 - 5).float().view(M, N)
+            pre = (torch.arange(M * N, device=DEV) % 7 - 3).to(torch.bfloat16).view(M, N)
+            outs += [ops.gemm_tn(a, w, ops.EPI_BF16, bias=bias), ops.gemm_tn(a, w, ops.EPI_F32_RESID, bias=bias, resid=resid)]
+            outs += list(ops.gemm_tn(a, w, ops.EPI_BF16_GELU, bias=bias, want_pre=True))
+            outs += list(ops.gemm_tn(a, w, ops.EPI_BF16_DGELU, pre=pre, want_colsum=True))
+            if N == 768:
+                assert torch.equal(outs[-6], ((a.float() @ w.float().t()) + bias).to(torch.bfloat16))
+        for (B, T, H) in [(43, 257, 12), (30, 513, 12)]:
+            g = torch.Generator().manual_seed(B + T)
+            qkv = (torch.randn(B * T, 3 * 64 * H, generator=g) * 1.5).to(torch.bfloat16).to(DEV)
+            dout = torch.randn(B * T, 64 * H, generator=g).to(torch.bfloat16).to(DEV)
+            o, lse = ops.attention_fwd(qkv, B, T, H)
+            outs += [x.clone() for x in ops.attention_bwd(qkv, o, dout, lse, B, T, H, want_colsum=True)]
+        return outs
+
+    assert ops.persistent_grid_size() == ncu
+    base = run_all()
+    old = ops.set_reserved_cus(r)
+    try:
+        assert old == 0
+        assert ops.persistent_grid_size() == (0 if r < 0 else ncu - (r + 7) // 8 * 8)
+        got = run_all()
+    finally:
+        ops.set_reserved_cus(0)
+    assert len(base) == len(got) and all(torch.equal(x, y) for x, y in zip(base, got))
+
+
 @pytest.mark.parametrize('B,T,runs', [(128, 513, 40), (256, 257, 20), (8, 2049, 10)])
 def test_attention_backward_is_bitwise_reproducible_under_load(B, T, runs):
     """A chip-filling launch repeated many times gives the same bits every time.  Regression for a barrier in the streaming
