@@ -460,7 +460,10 @@ static int g_wgrad_wide = 2;      // 0: 256x128 tiles, 1: 256x256, 2: 256x256 wi
 extern "C" int p4p_set_wgrad_wide(int v) { int o = g_wgrad_wide; g_wgrad_wide = v; return o; }
 static bool wgrad3_wide(int K) { return g_wgrad_wide && K % 256 == 0; }      // 256x256 tile, 8 waves, 1 workgroup per CU
 static int wgrad3_steps_per_split(int M, int N, int K) {
-    const int bk = wgrad3_wide(K) ? 256 : W3_BK, slots = wgrad3_wide(K) ? 256 : 512;
+    // one round of workgroups: as many M-splits as the resident slots allow -- the CUs p4p_set_reserved_cus() leaves (capi.cpp):
+    // with r CUs held by another kernel a grid of 256 would run 256 - r workgroups and then r more, i.e. take twice as long
+    const int pg = p4p_persistent_grid(), cus = pg > 0 ? pg : 256;
+    const int bk = wgrad3_wide(K) ? 256 : W3_BK, slots = wgrad3_wide(K) ? cus : 2 * cus;
     int tiles = (N / W3_BN) * (K / bk);
     int steps = ceil_div(M, 32);
     int want = slots / tiles;                      // one round: never more workgroups than resident slots

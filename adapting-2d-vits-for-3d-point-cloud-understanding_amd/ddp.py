@@ -179,20 +179,34 @@ class GradReducer:
         self.flat[s:e].zero_()
 
 
+RCCL_MAX_CHANNELS = 32
+
+
+def configure_rccl_env(max_channels=RCCL_MAX_CHANNELS):
+    """Call BEFORE init_process_group('nccl'): bounds the workgroups (= channels, one CU each) an RCCL collective may occupy, so
+    that the number of CUs to leave to it is KNOWN (reserve_cus_for_collectives).  A ViT-B gradient set is 345 MB per step behind
+    ~40 ms of backward: 32 channels are far more than the all-reduce needs to stay hidden.  An NCCL_MAX_NCHANNELS the user has set
+    is respected."""
+    os.environ.setdefault('NCCL_MAX_NCHANNELS', str(int(max_channels)))
+    return int(os.environ['NCCL_MAX_NCHANNELS'])
+
+
 def reserve_cus_for_collectives(world, reserved_cus=None):
-    """RCCL's all-reduce workgroups are long-lived and cannot share a CU with this library's one-workgroup-per-CU persistent
-    kernels (short-K GEMM tile loop, walking attention backward: every byte of LDS): a persistent workgroup that is dispatched
-    late still has its whole static share to do, so such a launch can take up to twice as long while an all-reduce is in flight.
-    At world > 1 those kernels therefore do not run persistently by default (a workgroup per tile / pair, balanced by the
-    hardware dispatcher over whatever CUs are free: +0.6 ms per 52-ms step on one GPU, tools/contention_rehearsal.py);
-    ``reserved_cus`` = r >= 0 (or P4P_RESERVED_CUS=r) keeps them persistent on CUs - r workgroups instead, the better choice once
-    the CU count RCCL holds has been measured on the node.  Returns the value set, None if untouched."""
+    """RCCL's all-reduce workgroups are long-lived and cannot share a CU with this library's kernels that size ONE round of
+    workgroups to the chip -- the persistent short-K GEMM tile loop, the walking attention backward (every byte of a CU's LDS)
+    and the weight-gradient GEMM's M-splits: with r CUs held, r of those workgroups start only when others have finished, with
+    their whole share still to do, and the launch takes twice as long.  One-GPU rehearsal with r parked stand-in workgroups
+    (tools/contention_rehearsal.py, N=1024 step, 51.4 ms alone): 72.2 ms with r = 8 and no remedy, 55.9 ms with all those grids
+    on CUs - r (p4p_set_reserved_cus), 62.1 ms with a workgroup per tile / pair (r < 0: the weight gradients keep 256 splits).
+    Default at world > 1: r = NCCL_MAX_NCHANNELS (configure_rccl_env: 32), i.e. what RCCL can take at most; r = 8 and r = 32
+    cost the same here (tile counts quantise alike).  ``reserved_cus`` / P4P_RESERVED_CUS override; world 1 leaves the library
+    alone.  Returns the value set, None if untouched."""
     if reserved_cus is None and 'P4P_RESERVED_CUS' in os.environ:
         reserved_cus = int(os.environ['P4P_RESERVED_CUS'])
     if reserved_cus is None:
         if world <= 1:
             return None
-        reserved_cus = -1
+        reserved_cus = int(os.environ.get('NCCL_MAX_NCHANNELS', RCCL_MAX_CHANNELS))
     from . import ops
     ops.set_reserved_cus(reserved_cus)
     return reserved_cus

@@ -517,6 +517,8 @@ def main():
             local = 0
         torch.cuda.set_device(local)
         if backend == 'nccl':
+            from p4p_amd.ddp import configure_rccl_env
+            configure_rccl_env()                        # bounds RCCL's channels (= CUs) before the communicator exists
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
         else:
             dist.init_process_group(backend)

@@ -188,7 +188,7 @@ int p4p_set_attention_variant(int v);      /* bit 0: no resident forward / dQ, b
  * counterpart: src/train/pix4point_trainer.py:4-6 imports DistributedDataParallel and never uses it).  The persistent tile loop of the
  * short-K GEMMs and the walking attention backward launch one workgroup per CU with a static share of the work; r CUs held by another
  * kernel would make r of them start late with their whole share to do.  r = 0 (default): all CUs; r > 0: CUs - r workgroups (r rounded
- * up to a multiple of 8), results bit-identical; r < 0: a workgroup per tile / pair (no persistent kernels).  Returns the previous
+ * up to a multiple of 8), GEMM / attention outputs bit-identical, the weight-gradient GEMM sizes its M-splits to one round of the same CUs - r workgroups (another fixed summation order); r < 0: a workgroup per tile / pair (no persistent kernels).  Returns the previous
  * value.  p4p_persistent_grid_size(): workgroups a persistent launch takes on the current device now (0: none are launched). */
 int p4p_set_reserved_cus(int r);
 int p4p_persistent_grid_size(void);

@@ -22,7 +22,7 @@ model_config = {
 }
 
 dataset_config = {
-    'root_dir': 'synthetic',       # the ScanObjectNN h5 reader is a later-round item
+    'root_dir': 'synthetic',       # or a ScanObjectNN directory (.h5 / .npz, p4p_amd.scanobjectnn: same file-name rules as the reference)
     'variant': 'main_split',
     'augmentation': 'augmentedrot_scale75',
     'train_num_points': 2048,
@@ -46,6 +46,8 @@ if __name__ == '__main__':
     if int(os.environ.get('WORLD_SIZE', '1')) > 1:
         local = int(os.environ.get('LOCAL_RANK', '0'))
         torch.cuda.set_device(local)
+        from p4p_amd.ddp import configure_rccl_env
+        configure_rccl_env()               # bounds RCCL's channels (= CUs) so that the library knows how many CUs to leave it
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     trainer = APFTrainer(model_config=model_config, dataset_config=dataset_config, train_config=train_config,
                          device='cuda', output_dir='./output_apf')
