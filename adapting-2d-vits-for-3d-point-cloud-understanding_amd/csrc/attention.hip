@@ -1206,10 +1206,11 @@ __global__ __launch_bounds__(RES_DKDV_NW * 64, 2) void attn_bwd_dkdv_res_kernel(
 
 #include "attention_lone.h"
 #include "attention_fused.h"
+#include "attention_fused2.h"
 
 // experiment switch for tools/attn_ab.py (in-process A/B, default 0 = automatic): bit 0 = no resident forward / dQ,
 // bit 1 = no resident dK/dV, bit 2 = no two-pass (64 n + 1) forward, bit 3 = no fused backward, bit 5 = no start shift of the
-// fused / key-stationary backward, bit 6 = no key-stationary dK/dV at T = 513, bit 7 = a workgroup per pair instead of the walk,
+// fused / key-stationary backward, bit 4 = no fused backward at T = 513 (attention_fused2.h), bit 6 = no key-stationary dK/dV at T = 513, bit 7 = a workgroup per pair instead of the walk,
 // bits 8-9 = start-shift phases - 1 and bits 10.. = shift in 1024-cycle units (sweeps).  Nothing in the product path sets it.
 static int g_attn_variant = 0;
 extern "C" int p4p_set_attention_variant(int v) { int o = g_attn_variant; g_attn_variant = v; return o; }
@@ -1320,6 +1321,32 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
         P4P_LAUNCH_CHECK();
     }
     dim3 grid = attn_grid(B, T, H);
+    if (T == 513 && !(g_attn_variant & (64 | 16)) && p4p_persistent_grid() > 0) {
+        // attention_fused2.h (round 4): dQ, dK, dV in ONE kernel -- a workgroup walks its pairs and takes the two key halves of a pair
+        // one after the other with Q / dO resident; half 0's dQ^T chains wait in a per-workgroup scratch (library-owned, 139 KB per
+        // workgroup).  Bit 4 of the variant: the two kernels below.
+        static float* scratch[64] = {nullptr};
+        static size_t scratch_floats[64] = {0};
+        int dev = 0;
+        P4P_HIP(hipGetDevice(&dev));
+        P4P_CHECK(dev >= 0 && dev < 64, "p4p_attention_bwd: device index %d", dev);
+        const int pgrid = p4p_persistent_grid();
+        const int nwg = B * H < pgrid ? B * H : pgrid;
+        const size_t need = (size_t)nwg * (F2Lds<16>::ROWS * 64);
+        if (need > scratch_floats[dev]) {
+            if (scratch[dev]) P4P_HIP(hipFree(scratch[dev]));
+            scratch[dev] = nullptr;
+            scratch_floats[dev] = 0;
+            P4P_HIP(hipMalloc(&scratch[dev], need * sizeof(float)));
+            scratch_floats[dev] = need;
+        }
+        p.stagger_n = nwg; p.stagger_phases = 3; p.stagger_cycles = 12 * 1024;
+        if (g_attn_variant & 32) p.stagger_phases = 1;
+        if (g_attn_variant >> 8) { p.stagger_phases = ((g_attn_variant >> 8) & 3) + 1; p.stagger_cycles = (g_attn_variant >> 10) * 1024; }
+        hipLaunchKernelGGL((attn_bwd_fused2_kernel<16, true>), dim3(nwg), dim3(512), 0, st, p, scratch[dev]);
+        P4P_LAUNCH_CHECK();
+        return 0;
+    }
     if (T == 513 && !(g_attn_variant & 64)) {            // streaming dQ (+ delta), then key-stationary dK / dV with Q, dO resident: attention_fused.h
         const int pg = p4p_persistent_grid();
         const int ncu = pg > 0 ? pg : 256;

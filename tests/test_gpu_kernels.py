@@ -507,6 +507,51 @@ def test_attention_backward_fused_kernels_against_the_two_kernel_path(B, T, H):
     assert (last <= tol.view(B, T, 3 * D)[:, T - 1]).all()
 
 
+@pytest.mark.parametrize('B,H', [(1, 1), (2, 12), (23, 12), (50, 6)])
+def test_attention_backward_fused_t513_against_the_kernels_it_replaces(B, H):
+    """Round 4: attn_bwd_fused2_kernel (T = 513: dQ, dK, dV in one kernel; a workgroup takes the two key halves of a pair one after the
+    other, half 0's dQ chains parked in a scratch) against attn_bwd_dq_q_kernel + attn_bwd_dkdv_ks_kernel (variant bit 4): the same
+    arithmetic contract, every element within single bf16 flips of the other path; the column sums are the sums of what
+    was stored; repeated launches are bitwise equal (the scratch is rewritten per pair); pair counts below / above / not a multiple
+    of the workgroup count; and the usual error against fp32 autograd."""
+    from p4p_amd import _lib
+    lib = _lib.lib()
+    T, D = 513, 64 * H
+    g = torch.Generator().manual_seed(513 + 7 * B + H)
+    qkv = (torch.randn(B * T, 3 * D, generator=g) * 1.5).to(torch.bfloat16).to(DEV)
+    dout = torch.randn(B * T, D, generator=g).to(torch.bfloat16).to(DEV)
+    out, lse = ops.attention_fwd(qkv, B, T, H)
+    try:
+        lib.p4p_set_attention_variant(16)
+        old, old_cs = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
+        old, old_cs = old.clone(), old_cs.clone()
+    finally:
+        lib.p4p_set_attention_variant(0)
+    new, new_cs = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
+    new, new_cs = new.clone(), new_cs.clone()
+    assert torch.isfinite(new.float()).all()
+    # delta = rowsum(dO . O) is summed in another order here (fma chains over two half rows, as in attn_bwd_fused_kernel; the
+    # streaming dQ kernel adds four 16-column groups), so dP differs in its last fp32 bit here and there and flips a bf16 rounding
+    # of dS now and then: dK / dV equal the key-stationary kernel's up to such single flips, dQ (another summation order of its
+    # keys on top) likewise
+    d = (new.float() - old.float()).abs()
+    tol = 4 * 2.0 ** -8 * torch.maximum(old.float().abs(), new.float().abs()) + 1e-3
+    assert (d <= tol).all(), float((d - tol).max())
+    assert float((d[:, D:] > 0).float().mean()) < 0.02        # dK, dV: almost all elements bit-identical
+    assert float((d[:, :D] > 0).float().mean()) < 0.10
+    want = new.double().sum(0)
+    assert (new_cs.double() - want).abs().max().item() <= 1e-5 * max(new.float().abs().sum(0).max().item(), 1.0)
+    for _ in range(3):
+        again, again_cs = ops.attention_bwd(qkv, out, dout, lse, B, T, H, want_colsum=True)
+        assert torch.equal(again, new) and torch.equal(again_cs, new_cs)
+    nb = min(B, 2)
+    for sl in (slice(0, nb * T), slice((B - nb) * T, B * T)):
+        qr = qkv[sl].float().requires_grad_(True)
+        _attn_ref(qr, nb, T, H).backward(dout[sl].float())
+        sc = max(qr.grad.abs().max().item(), 1.0)
+        assert (new[sl].float() - qr.grad).abs().max().item() <= 3e-2 * sc
+
+
 @pytest.mark.parametrize('B,H', [(43, 6), (25, 12), (300, 1), (23, 12)])
 def test_attention_backward_persistent_walk_equals_a_workgroup_per_pair(B, H):
     """T = 257 with more (batch, head) pairs than CUs: one workgroup per CU WALKS its pairs (the default).  Bit for bit what a
@@ -576,7 +621,16 @@ def test_persistent_kernels_on_fewer_cus_are_bit_identical(r):
         got = run_all()
     finally:
         ops.set_reserved_cus(0)
-    assert len(base) == len(got) and all(torch.equal(x, y) for x, y in zip(base, got))
+    assert len(base) == len(got)
+    for j, (x, y) in enumerate(zip(base, got)):
+        if r < 0 and j >= len(base) - 2:
+            # without persistent kernels T = 513 runs the streaming dQ + key-stationary dK/dV pair instead of the fused kernel
+            # (attention_fused2.h walks by construction): the same contract, single bf16 flips apart
+            dd = (x.float() - y.float()).abs()
+            lim = 4 * 2.0 ** -8 * torch.maximum(x.float().abs(), y.float().abs()) + (1e-3 if x.dtype == torch.bfloat16 else 0.5)
+            assert (dd <= lim).all(), (j, float((dd - lim).max()))
+        else:
+            assert torch.equal(x, y), j
 
 
 @pytest.mark.parametrize('B,T,runs', [(128, 513, 40), (256, 257, 20), (8, 2049, 10)])

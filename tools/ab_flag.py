@@ -1,5 +1,5 @@
 """Runs bench.py with module attributes of the package overridden (same-box A/B of a host-side change in one gpurun call):
-    python tools/ab_flag.py functional._POS_GRAD_SLABS=0 [bench.py arguments]"""
+    python tools/ab_flag.py functional._FUSE_QKV_BIAS_MAXT=0 [bench.py arguments]"""
 import importlib, os, runpy, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
