@@ -15,6 +15,7 @@ from . import ops
 # token streams, per block: xin / ln1 / qkv / att / x1 / ln2 / g / xout, and the final LayerNorm output), so that a PyTorch
 # statement can be checked LINK BY LINK against the pipeline's own upstream tensors (tests/test_gpu_matched_parity.py)
 _CAPTURE = None
+_CAPTURE_BWD = None        # tests only: a dict that the encoder's backward fills with every block's upstream gradient
 
 
 def _bf16_weights(w, want_t, col0=0, cols=None):
@@ -378,7 +379,7 @@ class _EncoderFn(torch.autograd.Function):
                 saved += [xin, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, hpre, g]
             if _CAPTURE is not None:
                 _CAPTURE.setdefault('blocks', []).append(dict(xin=xin, ln1=ln1, qkv=qkv, att=att, x1=x1, ln2=ln2, g=g, xout=x,
-                                                              pos_added=l + 1 < L))
+                                                              pos_added=l + 1 < L, lse=lse))
         y, _, meanN, rstdN = ops.layernorm_fwd(x, norm_w.detach(), norm_b.detach(), eps, out_f32=True, want_stats=train)
         if _CAPTURE is not None:
             _CAPTURE['encoder_out'] = y
@@ -415,6 +416,8 @@ class _EncoderFn(torch.autograd.Function):
         for l in reversed(range(L)):
             n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = bp[l * _BLOCK_PARAMS:(l + 1) * _BLOCK_PARAMS]
             xin, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, hpre, g = saved[l * 13:(l + 1) * 13]
+            if _CAPTURE_BWD is not None:     # tests: the upstream gradient of every block (teacher-forced per-block backward checks)
+                _CAPTURE_BWD.setdefault('block_dout', {})[l] = dx.detach().clone()
             wg = need[8 + l * _BLOCK_PARAMS + 2]       # block weights trainable? (frozen ViT => False)
             # data parallel: the weight-gradient GEMMs write straight into the reducer's flat buffer (ddp.GradReducer)
             dst = sink.grad_views(bp[l * _BLOCK_PARAMS:(l + 1) * _BLOCK_PARAMS]) if (wg and sink is not None) else None
@@ -460,6 +463,8 @@ class _EncoderFn(torch.autograd.Function):
                 if sink is not None:
                     grads[l * _BLOCK_PARAMS:(l + 1) * _BLOCK_PARAMS] = sink.block_ready(
                         l, bp[l * _BLOCK_PARAMS:(l + 1) * _BLOCK_PARAMS], grads[l * _BLOCK_PARAMS:(l + 1) * _BLOCK_PARAMS])
+        if _CAPTURE_BWD is not None:
+            _CAPTURE_BWD['encoder_din'] = dx.detach().clone()
         dpos = ops.sum_slabs(dstack) if L else torch.zeros(M, D, dtype=torch.float32, device=dev)
         return (dx.view(B, T, D), dpos.view(B, T, D), None, None, None, None, dnw, dnb, *grads)
 

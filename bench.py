@@ -422,6 +422,20 @@ def spawn_ranks(args):
 LAST_ENQUEUE_S = [0.0]
 
 
+def host_enqueue_ms(stepper, batch, reps=3):
+    """Host time to ENQUEUE one training step into an EMPTY queue (device drained before and after; median of `reps`).  Measured
+    over a long timed region instead, the figure saturates at the device time as soon as the launch queue is full (the host blocks in
+    the launch call), so it could not tell a host-bound step from a device-bound one with the host running ahead."""
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        stepper.step(*batch)
+        ts.append(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+    return sorted(ts)[len(ts) // 2] * 1e3
+
+
 def timed_steps(stepper, batch, steps, fence, distributed, device, optim=True):
     """EXACTLY `steps` steps between two fences (barrier + device synchronize); seconds, max over ranks, and every
     rank's own time."""
@@ -546,8 +560,8 @@ def main():
     for _ in range(args.warmup):
         stepper.step(*batch)
     elapsed, per_rank, loss_val = timed_steps(stepper, batch, args.steps, fence, distributed, device)
-    host_enqueue_ms = LAST_ENQUEUE_S[0] / args.steps * 1e3
-    log(f'timed region: {args.steps} steps in {elapsed:.3f} s (host enqueue {LAST_ENQUEUE_S[0]:.3f} s)')
+    log(f'timed region: {args.steps} steps in {elapsed:.3f} s (host returned from the last enqueue after {LAST_ENQUEUE_S[0]:.3f} s)')
+    host_enq = host_enqueue_ms(stepper, batch)
     # the metric's literal "fwd+bwd" (no clip / AdamW), SURVEY.md section 8d's first figure: the same K steps again
     fb_elapsed, _, _ = timed_steps(stepper, batch, args.steps, fence, distributed, device, optim=False)
 
@@ -573,7 +587,7 @@ def main():
             stepper.step(*ns_batch)
         ns_steps = 10
         ns_el, _, _ = timed_steps(stepper, ns_batch, ns_steps, fence, False, device)
-        ns_enq = LAST_ENQUEUE_S[0] / ns_steps * 1e3
+        ns_enq = host_enqueue_ms(stepper, ns_batch)
         ns_fb, _, _ = timed_steps(stepper, ns_batch, 5, fence, False, device, optim=False)
         ns_roof = instrumented_roofline(stepper, ns_batch, 2, attn_dims=(nb, npts // 4 + 1, vd)) if not args.no_roofline else None
         fl = flop_per_cloud(npts, vd, vl)
@@ -608,14 +622,14 @@ def main():
         runs = []
         for _ in range(3):                              # three timed regions of 20 steps: the scatter between them is reported
             el2, _, _ = timed_steps(st2, b2, k_steps, fence, False, device)
-            runs.append((el2 / k_steps * 1e3, LAST_ENQUEUE_S[0] / k_steps * 1e3))
+            runs.append(el2 / k_steps * 1e3)
         runs.sort()
-        ms2, enq2 = runs[1]                             # median region
+        ms2, enq2 = runs[1], host_enqueue_ms(st2, b2)   # median region
         fl2 = flop_per_cloud(a2.points, ld_, ll_)
         v2 = a2.batch / (ms2 * 1e-3)
         n8k = {'workload': f'Pix4Point {a2.vit} (D={ld_}, {ll_} blocks, {lh_} heads) N=8192 k=16, batch {a2.batch}, 1 GPU (same step as the headline line)',
-               'clouds_per_sec': v2, 'ms_per_step': ms2, 'steps': k_steps, 'ms_per_step_runs': [r[0] for r in runs],
-               'scatter_pct': (runs[-1][0] - runs[0][0]) / ms2 * 50.0,      # +- half of the range, in % of the median
+               'clouds_per_sec': v2, 'ms_per_step': ms2, 'steps': k_steps, 'ms_per_step_runs': runs,
+               'scatter_pct': (runs[-1] - runs[0]) / ms2 * 50.0,      # +- half of the range, in % of the median
                'host_enqueue_ms_per_step': enq2,
                'algorithmic_gflop_per_cloud': fl2 * 1e-9, 'algorithmic_tflops': v2 * fl2 * 1e-12,
                'mfma_frac_whole_step': v2 * fl2 * 1e-12 / PEAK_BF16_TFLOPS}
@@ -665,7 +679,7 @@ def main():
             'fwd_bwd_only': {'value': clouds / fb_elapsed, 'unit': 'point-clouds/sec',
                              'ms_per_step': fb_elapsed / args.steps * 1e3, 'steps': args.steps},
             'per_rank_ms_per_step': [t / args.steps * 1e3 for t in per_rank],
-            'host_enqueue_ms_per_step': host_enqueue_ms,      # rank 0's host time to enqueue a step; ~= ms_per_step means host-bound
+            'host_enqueue_ms_per_step': host_enq,      # rank 0's host time to enqueue ONE step into an empty queue; >= ms_per_step means host-bound
         }
         if ddp_info is not None:
             out['ddp'] = ddp_info

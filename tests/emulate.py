@@ -22,7 +22,10 @@ def _bn_train(h, gamma, beta, eps):
 
 
 LINK_LIMITS = {'bf16': 0.05,     # ulps beyond a correct rounding (after the fp32 summation slack, link_stats)
-               'att': 0.6,       # units of max(ulp, 2^-8 rms): half an output ulp + the P roundings inside the kernel (measured 0.51)
+               'att': 3.0,       # flipped numerators of the row beyond half an output ulp (link_stats 'att'): the bound that holds for ALL
+                                 # inputs (tests/tools/fuzz_kernels.py: 376 random shapes; the model's own activations measure 0.0-0.3);
+                                 # rounds 2-3 had 0.6 x max(ulp, 2^-8 rms) here, a statistic of the suite's fixed seeds that one random
+                                 # peaked softmax in ten exceeds through a single numerator rounded the other way
                'f32': 3e-5,      # relative to the tensor's rms
                'exact': 0.0}
 NORTH_STAR_TOL = 1e-3            # BASELINE.json north_star: "logits within 1e-3"
@@ -36,8 +39,8 @@ def assert_links(oracle, cap, pts, idx_fps, idx_knn, logits, training=False, gra
     with torch.set_grad_enabled(grad):
         stated = pix4point_emulated(oracle, pts, idx_fps, idx_knn, training=training, tape=tape)
     bad, worst = [], {}
-    for name, got, want, kind in tape.links:
-        v = link_stats(got, want, kind)
+    for name, got, want, kind, *unit in tape.links:
+        v = link_stats(got, want, kind, *unit)
         worst[name] = v
         if not v <= LINK_LIMITS[kind]:
             bad.append((name, kind, v))
@@ -67,12 +70,13 @@ class Tape:
             return self.cap['blocks'][int(grp[5:])][key]
         return self.cap[grp][key]
 
-    def __call__(self, name, v, kind):
-        """kind: 'bf16' (stored bf16), 'att' (bf16, but with roundings of its own inside), 'f32', 'exact'."""
+    def __call__(self, name, v, kind, unit=None):
+        """kind: 'bf16' (stored bf16), 'att' (bf16, but with roundings of its own inside; unit = what one flipped numerator moves an
+        element by, attention_flip_unit), 'f32', 'exact'."""
         if self.cap is None:
             return _r(v) if kind in ('bf16', 'att') else v
         got = (self.cap[name] if '.' not in name else self._captured(name)).detach().reshape(v.shape).float()
-        self.links.append((name, got, v.detach(), kind))
+        self.links.append((name, got, v.detach(), kind) if unit is None else (name, got, v.detach(), kind, unit))
         return v + (got - v).detach()
 
 
@@ -219,6 +223,61 @@ def attention_emulated(qkv, B, T, H, round_output=True):
     return out.permute(0, 2, 1, 3).reshape(B * T, H * hd)
 
 
+def attention_backward_emulated(qkv, o, dout, lse2, B, T, H, key_chunk=256):
+    """The attention BACKWARD as every backward kernel of csrc/attention*.h evaluates it (one contract for the streaming, resident,
+    fused and T = 513 kernels): with S = q k^T, c = scale log2(e) and the FORWARD's lse2 (teacher-forced: the kernels read it too),
+        P  = exp2(fma(S, c, -lse2))           fp32          delta = rowsum(dO . O)   from the bf16 tensors, fp32
+        dP = dO v^T - delta                   fp32          dS    = P dP             fp32 (the unrounded P)
+        dV = round_bf16(P)^T dO               dK = scale round_bf16(dS)^T q          dQ = scale round_bf16(dS) k
+    i.e. P and dS are rounded to bf16 exactly where they enter a matrix product, everything else is fp32 (scale = 2^-3 at head_dim 64
+    commutes with the rounding).  qkv [B*T, 3D], o / dout [B*T, D] bf16-valued, lse2 [B,H,T].
+    Returns (dqkv fp32 [B*T, 3D] BEFORE the final rounding to bf16, unit [B*T, 3D]): unit = what ONE numerator rounded the other way
+    can move that element by, max over the contraction index of ulp(x_k) |y_k| (x = P or dS).  Two correct implementations differ by
+    half an output ulp plus a few such flips (v_exp_f32 against torch.exp2, the summation order of delta and of the 64-term dot
+    products in front of a rounding)."""
+    hd = 64
+    D = H * hd
+    scale = hd ** -0.5
+    c = float(torch.tensor(scale, dtype=torch.float32) * torch.tensor(LOG2E, dtype=torch.float32))
+    x = qkv.float().view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = x[0], x[1], x[2]                                          # [B,H,T,hd]
+    do = dout.float().view(B, T, H, hd).permute(0, 2, 1, 3)
+    oo = o.float().view(B, T, H, hd).permute(0, 2, 1, 3)
+    s = q @ k.transpose(-1, -2)
+    p = _exp2_fma(s, c, lse2.float().view(B, H, T, 1))
+    delta = (do * oo).sum(-1, keepdim=True)
+    dp = do @ v.transpose(-1, -2) - delta
+    ds = p * dp
+    pb, dsb = p.to(torch.bfloat16).float(), ds.to(torch.bfloat16).float()
+    dq = (dsb @ k) * scale
+    dk = (dsb.transpose(-1, -2) @ q) * scale
+    dv = pb.transpose(-1, -2) @ do
+    up, uds = bf16_ulp(p), bf16_ulp(ds)
+
+    def maxprod(a, y):
+        """[.., R, C] x [.., R, hd] -> [.., C, hd]: max over R of a[r, c] |y[r, d]| (chunked over C)"""
+        outs = []
+        for c0 in range(0, a.shape[-1], key_chunk):
+            outs.append((a[..., :, c0:c0 + key_chunk].transpose(-1, -2).unsqueeze(-1) * y.abs().unsqueeze(-3)).amax(dim=-2))
+        return torch.cat(outs, dim=-2)
+
+    unit_q = maxprod(uds.transpose(-1, -2), k) * scale                  # rows = keys (contraction), columns = queries
+    unit_k = maxprod(uds, q) * scale                                    # rows = queries (contraction), columns = keys
+    unit_v = maxprod(up, do)
+    pack = lambda t3: torch.stack(t3, 0).permute(1, 3, 0, 2, 4).reshape(B * T, 3 * D)      # [3,B,H,T,hd] -> [B*T, 3, H, hd]
+    return pack((dq, dk, dv)), pack((unit_q, unit_k, unit_v))
+
+
+def flips_beyond_rounding(got, want, unit):
+    """How many single flipped numerators (units of `unit`) the worst element of a stored bf16 tensor is away from a correct rounding
+    of the stated fp32 value `want`: max over elements of (|got - want| - ulp(want) / 2 - 2e-5 rms) / unit, never below 0."""
+    got, want = got.detach().float(), want.detach().float()
+    d = (got - want).abs()
+    rms = float(want.pow(2).mean().sqrt())
+    excess = (d - 0.5 * bf16_ulp(want) - 2e-5 * rms).clamp_min(0)
+    return float((excess / unit.clamp_min(1e-30)).max())
+
+
 def _ln(x, w, b, eps):
     return torch.nn.functional.layer_norm(x, (x.shape[-1],), w, b, eps)
 
@@ -237,15 +296,49 @@ def encoder_emulated(feats, pos, blocks, norm, H, tape=None):
     L = len(blocks)
     for l, blk in enumerate(blocks):
         xin = tape(f'block{l}.xin', x + pos2, 'f32') if l == 0 else x
-        ln1 = tape(f'block{l}.ln1', _ln(xin, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps), 'bf16')
-        qkv = tape(f'block{l}.qkv', ln1 @ _r(blk.attn.qkv.weight).t() + blk.attn.qkv.bias, 'bf16')
-        att = tape(f'block{l}.att', attention_emulated(qkv, B, T, H, round_output=False), 'att')
-        x1 = tape(f'block{l}.x1', att @ _r(blk.attn.proj.weight).t() + blk.attn.proj.bias + xin, 'f32')
-        ln2 = tape(f'block{l}.ln2', _ln(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), 'bf16')
-        g = tape(f'block{l}.g', _gelu(ln2 @ _r(blk.mlp.fc1.weight).t() + blk.mlp.fc1.bias), 'bf16')
-        x = g @ _r(blk.mlp.fc2.weight).t() + blk.mlp.fc2.bias + x1
+        x = block_emulated(xin, blk, B, T, H, tape, l)
         x = tape(f'block{l}.xout', x + pos2 if l + 1 < L else x, 'f32')
     return tape('encoder_out', _ln(x, norm.weight, norm.bias, norm.eps), 'f32').view(B, T, D)
+
+
+class _AttentionMatchedBackward(torch.autograd.Function):
+    """attention_emulated in the forward; in the backward the kernels' own contract (attention_backward_emulated: P and dS rounded to
+    bf16 where they enter a product, delta from the stored bf16 output, the forward's lse2) instead of the exact fp32 gradient.  The
+    two differ by the rounding of dS, which the sum over the keys amplifies wherever the key rows share a large common component
+    (sum_k dS_k = 0 cancels it in exact arithmetic, not in the rounding noise): 4-8 % on the qkv / norm1 gradients of a randomly
+    initialised ViT-B -- a property of ANY bf16 flash-style backward, not of these kernels."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, T, H, o_stored, lse2):
+        ctx.save_for_backward(qkv.detach(), o_stored.detach(), lse2.detach())
+        ctx.dims = (B, T, H)
+        with torch.no_grad():
+            return attention_emulated(qkv.detach(), B, T, H, round_output=False)
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, o, lse2 = ctx.saved_tensors
+        B, T, H = ctx.dims
+        with torch.no_grad():
+            dqkv, _ = attention_backward_emulated(qkv, o, dout.to(torch.bfloat16).float(), lse2, B, T, H)
+        return dqkv.to(torch.bfloat16).float(), None, None, None, None, None      # the pipeline stores dqkv in bf16
+
+
+def block_emulated(xin, blk, B, T, H, tape, l=0, matched_attention_backward=None):
+    """One transformer block (timm Block layout) on xin [B*T, D] = the block's input INCLUDING the positional embedding; returns
+    x1 + fc2(gelu(fc1(ln2(x1)))) with x1 = xin + proj(attention(qkv(ln1(xin)))), hand-offs named block{l}.* on the tape.
+    matched_attention_backward = (stored attention output bf16, lse2 [B,H,T]) of the pipeline: autograd then runs the attention
+    backward in the kernels' contract (_AttentionMatchedBackward) instead of the exact fp32 gradient."""
+    ln1 = tape(f'block{l}.ln1', _ln(xin, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps), 'bf16')
+    qkv = tape(f'block{l}.qkv', ln1 @ _r(blk.attn.qkv.weight).t() + blk.attn.qkv.bias, 'bf16')
+    if matched_attention_backward is not None:
+        att = tape(f'block{l}.att', _AttentionMatchedBackward.apply(qkv, B, T, H, *matched_attention_backward), 'att', unit=attention_flip_unit(qkv, B, T, H))
+    else:
+        att = tape(f'block{l}.att', attention_emulated(qkv, B, T, H, round_output=False), 'att', unit=attention_flip_unit(qkv, B, T, H))
+    x1 = tape(f'block{l}.x1', att @ _r(blk.attn.proj.weight).t() + blk.attn.proj.bias + xin, 'f32')
+    ln2 = tape(f'block{l}.ln2', _ln(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps), 'bf16')
+    g = tape(f'block{l}.g', _gelu(ln2 @ _r(blk.mlp.fc1.weight).t() + blk.mlp.fc1.bias), 'bf16')
+    return g @ _r(blk.mlp.fc2.weight).t() + blk.mlp.fc2.bias + x1
 
 
 def pix4point_emulated(oracle, pts, idx_fps, idx_knn, training=False, tape=None):
@@ -282,13 +375,24 @@ def bf16_ulp(v):
     return torch.exp2(torch.floor(torch.log2(v.abs().clamp_min(2.0 ** -100))) - 7)
 
 
-def link_stats(got, want, kind):
+def attention_flip_unit(qkv, B, T, H):
+    """[B*T, H*64]: what ONE softmax numerator rounded to bf16 the other way can move an attention output element by -- 2^-9 times the
+    row's largest probability times the largest |v| of the column (tests/tools/fuzz_kernels.py: every output of 376 random shapes within
+    half an ulp + three of these)."""
+    with torch.no_grad():
+        q, k, v = qkv.detach().float().view(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+        pmax = torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1).amax(-1)              # (B,H,T)
+        vmax = v.abs().amax(2, keepdim=True)                                            # (B,H,1,64)
+        return (2.0 ** -9) * (pmax.unsqueeze(-1) * vmax).permute(0, 2, 1, 3).reshape(B * T, H * 64)
+
+
+def link_stats(got, want, kind, unit=None):
     """One number per link, to be bounded by the caller.
     'bf16': got is a stored bf16 tensor, want the stated fp32 value before rounding -> worst excess over half an ulp, in
             ulps, after an absolute slack of 2e-5 x the tensor's rms (fp32 summation order on cancelling sums: 200 times
             below the bf16 spacing at the rms);
     'att' : attention output: its roundings of P happen inside the kernel, so one flipped P moves an output by up to
-            2^-8 p |v|: worst |difference| in units of max(ulp(want), 2^-8 rms);
+            2^-8 p |v|: with `unit` (attention_flip_unit) the number of flipped numerators of the row beyond half an output ulp;
     'f32' : worst |difference| relative to the tensor's rms;  'exact': number of differing elements."""
     got, want = got.detach().float(), want.detach().float()
     d = (got - want).abs()
@@ -298,7 +402,9 @@ def link_stats(got, want, kind):
     if kind == 'f32':
         return float(d.max()) / max(rms, 1e-30)
     if kind == 'att':
-        return float((d / torch.clamp(bf16_ulp(want), min=rms * 2.0 ** -8)).max())
+        if unit is None:                    # (rounds 2-3: worst difference in units of max(ulp, 2^-8 rms): a seed-dependent statistic)
+            return float((d / torch.clamp(bf16_ulp(want), min=rms * 2.0 ** -8)).max())
+        return float(((d - 0.5 * bf16_ulp(want) - 1e-6).clamp_min(0) / unit.clamp_min(1e-30)).max())
     excess = (d - 2e-5 * rms - 0.5 * bf16_ulp(want)).clamp_min(0) / bf16_ulp(want)
     return float(excess.max())
 
