@@ -423,7 +423,9 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_fused2_kernel(AttnParams p, f
             bf16x8 pb[2], db[2];
             f32x16 dsf;
             front(row0, kf, vf, pb, db, dsf);
+#ifndef P4P_F2_NO_B                                    // (timing-only diagnostic: what the second barrier of a tile costs; racy without it)
             if (qt > 0) __syncthreads();               // [B] every wave has read the previous tile's dS image
+#endif
             {                                          // dS tile -> image [key][32 q]: registers 4 jj .. 4 jj + 3 = rows 8 jj + 4 h ..
                 const u32x4 w0 = __builtin_bit_cast(u32x4, db[0]), w1 = __builtin_bit_cast(u32x4, db[1]);
                 const u32 words[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};

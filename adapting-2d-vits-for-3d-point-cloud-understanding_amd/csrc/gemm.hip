@@ -38,6 +38,8 @@ static int g_gemm_variant = 0;
 static int g_tn4_persistent = 1;            // A/B switch: 0 = one workgroup per tile (gemm_tn4.h) everywhere; bit 1: no banded tile order
 extern "C" int p4p_set_gemm_persistent(int v) { int o = g_tn4_persistent; g_tn4_persistent = v; return o; }
 extern "C" int p4p_set_gemm_variant(int v) { int o = g_gemm_variant; g_gemm_variant = v; return o; }
+static int g_epi_flags = 0;                 // A/B switch: bit 0 = epilogue loads as hipcc counts them (gemm_tn3.h: epi_resid_full off)
+extern "C" int p4p_set_gemm_epilogue(int v) { int o = g_epi_flags; g_epi_flags = v; return o; }
 
 // ---- split-K for the short, wide tail launches (few workgroups, long K loop: latency-bound at one K-step per ~0.5 us)
 // out[m][n] = sum_s part[s][m][n] + bias[n] (+ resid[m][n]), fixed order; fp32 or bf16 output
@@ -259,7 +261,7 @@ extern "C" int p4p_gemm_tn_bf16(int epi, const void* A, const void* W, void* out
     P4P_CHECK(N % 8 == 0, "p4p_gemm_tn_bf16: N=%d must be a multiple of 8", N);
     GemmParams p;
     p.A = (const __bf16*)A; p.W = (const __bf16*)W; p.out = out; p.bias = bias; p.resid = resid;
-    p.pre = (__bf16*)pre; p.rowgrp = rowgrp; p.stats = stats; p.M = M; p.N = N; p.K = K; p.group = group; p.ldk = K; p.band = 0;
+    p.pre = (__bf16*)pre; p.rowgrp = rowgrp; p.stats = stats; p.M = M; p.N = N; p.K = K; p.group = group; p.ldk = K; p.band = 0; p.epi_flags = g_epi_flags;
     hipStream_t st = (hipStream_t)stream;
     struct ProfScope {      // gemm_tn: brackets the (one or two, when the tail is peeled) launches of this call
         hipStream_t s; bool on;

@@ -52,7 +52,68 @@ struct T3Frags {
 //     pieces into 16-B stores of whole 128-B row segments.
 // The caller guarantees that no wave reads the operand ring any more (the slabs live at `lds`, 4.5 KiB per wave).
 // =================================================================================================
-template <int EPI, bool LDS_FREE = false>
+// ---- fp32-residual epilogue (round 4): a ring of D slabs of residual in flight ---------------------------------------------------
+// tools/gemm_stamps.py (s_memtime stamps per wave and tile, M = 65,792): the fp32-residual epilogue of the proj GEMM took 45k cycles of
+// a tile's 80k (K loop: 30k) for 256 KB read + 256 KB written -- 11.6 B/clk, half the rate of the plain bf16 epilogue.  The ISA says
+// why: the residual of slab j + 1 was asked for one slab ahead, but in the persistent kernel the LDS-DMAs of the seam are in the queue
+// during the epilogue, and with a DMA outstanding hipcc does not count its own loads: it waited `vmcnt(3 / 2 / 1 / 0)` in front of slab
+// j's additions, i.e. for the loads of slab j + 1 it had just issued -- a full memory round trip per slab, eight per tile.
+// Two changes: (i) gemm_tn4p.h drains the seam's DMAs once in front of the epilogue (they were issued two K-tiles earlier: landed or
+// nearly), after which hipcc counts exactly; (ii) D slabs of residual in flight instead of one.
+// (A form with the loads in inline asm and hand-counted `s_waitcnt vmcnt(n_j)` was built first: wrong results -- at 256 VGPRs hipcc
+// copies a ring register between the asm load and the asm wait, i.e. before the data has landed; guides' section 5.7 item 1.)
+template <int NS, int D>      // NS residual streams: 0, 1 (x1 = xin + proj(..)) or 2 (x = x1 + fc2(..) + pos); D slabs of them in flight
+__device__ __forceinline__ void epi_resid_rows(const GemmParams& p, f32x4 (&acc)[4][8], char* fslab, const f32x4 (&bias4)[4], int rowbase,
+                                               int colbase, int lane) {
+    constexpr int FS = 272, L = 4 * NS, S = 4;
+    const int li = lane & 15, g = lane >> 4, rr = lane >> 4, cc = lane & 15;
+    const float* q[2] = {NS >= 1 ? p.resid + (size_t)colbase + cc * 4 : nullptr, NS == 2 ? p.rowgrp + (size_t)colbase + cc * 4 : nullptr};
+    float* outp = (float*)p.out + (size_t)colbase + cc * 4;
+    f32x4 ring[NS ? D : 1][NS ? NS : 1][4];
+    auto issue = [&](int j, int slot) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                int m = rowbase + j * 16 + h * 4 + rr;
+                m = m < p.M ? m : p.M - 1;
+                ring[slot][s][h] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q[s] + (size_t)m * p.N));      // read once
+            }
+    };
+    if constexpr (NS > 0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) issue(d, d);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(fslab + li * FS + i * 64 + g * 16) = acc[i][j] + bias4[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int m = rowbase + j * 16 + h * 4 + rr;
+            f32x4 v = *reinterpret_cast<const f32x4*>(fslab + (h * 4 + rr) * FS + cc * 16);
+            if constexpr (NS == 1) v = v + ring[j % D][0][h];
+            if constexpr (NS == 2) v = v + (ring[j % D][0][h] + ring[j % D][1][h]);
+            if (m < p.M) {
+                // group = S > 1: token-stream output, row m of the compact [B*S] rows goes to row m + m/S + 1 ([B*(S+1)] rows, one cls
+                // row in front of every sequence: src/models/pix4point.py:248-252 without the torch.cat); never with a residual
+                const size_t orow = (NS == 0 && p.group > 1) ? (size_t)m + m / p.group + 1 : (size_t)m;
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(outp + orow * p.N));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (NS > 0) {
+            if (j + D < 8) issue(j + D, j % D);
+        }
+    }
+}
+
+template <int EPI, bool LDS_FREE = false, bool FAST_TWO_STREAMS = true>     // FAST_TWO_STREAMS: false in the persistent kernel (never launched with a second residual; the 64 ring registers spill there)
 __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 (&acc)[4][8], char* wslab, int tm, int m0,
                                                      int n0, int wm, int wn, int wave, int lane,
                                                      const f32x4* bias_pre = nullptr) {      // wslab: this wave's 4.5 KiB
@@ -76,50 +137,12 @@ __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 
         float* dst = (float*)p.out + (size_t)colbase + g * 4;
         auto row_of = [&](int j) { int m = rowbase + j * 16 + li; return m < p.M ? m : p.M - 1; };
         if constexpr (LDS_FREE) {
-            // rows through the wave's LDS slab: every global access (residual reads, output stores) is 4 whole 256-B row
-            // segments per instruction instead of 16 rows x 64 B; the sums keep their association ((acc + bias) + resid)
-            constexpr int FS = 272;                          // 256-B rows + 16
-            char* fslab = wslab;
-            const int rr = lane >> 4, cc = lane & 15;
-            const float* q1 = p.resid ? p.resid + (size_t)colbase + cc * 4 : nullptr;
-            const float* q2 = p.rowgrp ? p.rowgrp + (size_t)colbase + cc * 4 : nullptr;
-            auto row_at = [&](int j, int h) { int m = rowbase + j * 16 + h * 4 + rr; return m < p.M ? m : p.M - 1; };
-            // the two residual streams stay in separate registers until the slab that uses them: adding them at fetch time made
-            // hipcc wait for both loads on the spot (vmcnt(0) four times per slab, one slab ahead of need)
-            f32x4 nxt[4], nxt2[4];
-            auto fetch = [&](int j) {
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    nxt[h] = q1 ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q1 + (size_t)row_at(j, h) * p.N)) : f32x4{0.f, 0.f, 0.f, 0.f};   // read once
-                    nxt2[h] = q2 ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q2 + (size_t)row_at(j, h) * p.N)) : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            };
-            fetch(0);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                f32x4 cur[4];
-#pragma unroll
-                for (int h = 0; h < 4; ++h) cur[h] = q2 ? nxt[h] + nxt2[h] : nxt[h];
-                if (j + 1 < 8 && q1) fetch(j + 1);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    *reinterpret_cast<f32x4*>(fslab + li * FS + i * 64 + g * 16) = acc[i][j] + bias4[i];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const int m = rowbase + j * 16 + h * 4 + rr;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(fslab + (h * 4 + rr) * FS + cc * 16) + cur[h];
-                    if (m < p.M) {
-                        const size_t orow = p.group > 1 ? (size_t)m + m / p.group + 1 : (size_t)m;
-                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>((float*)p.out + orow * p.N + colbase + cc * 4));
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
+            // rows through the wave's LDS slab: every global access (residual reads, output stores) is 4 whole 256-B row segments per
+            // instruction instead of 16 rows x 64 B; the sums keep their association ((acc + bias) + (resid + resid2)); residual loads
+            // hand-counted (epi_resid_rows).  p.epi_flags bit 0 (A/B switch) has no effect here any more: the round-3 form is gone.
+            if (!p.resid) epi_resid_rows<0, 1>(p, acc, wslab, bias4, rowbase, colbase, lane);
+            else if (!p.rowgrp) epi_resid_rows<1, FAST_TWO_STREAMS ? 3 : 2>(p, acc, wslab, bias4, rowbase, colbase, lane);
+            else epi_resid_rows<2, 2>(p, acc, wslab, bias4, rowbase, colbase, lane);
             return;
         }
         f32x4 rnext[4];
@@ -186,7 +209,8 @@ __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 
     // accumulator layout (16 rows x 32 B per instruction)
     constexpr bool HROWS = LDS_FREE && EPI == EPI_BF16_DGELU;
     bf16x4 hnext[4];
-    u32x4 hrows[2];
+    constexpr int HD_ = 3;                                  // slabs of gelu' in flight (HROWS; round 4: one was a memory round trip per slab)
+    u32x4 hring[HD_][2];
     const __bf16* hsrc = EPI == EPI_BF16_DGELU ? p.pre + (size_t)colbase + g * 4 : nullptr;
     const __bf16* hsrc_r = EPI == EPI_BF16_DGELU ? p.pre + (size_t)colbase + (lane & 7) * 8 : nullptr;
     auto hrow = [&](int j) { int m = rowbase + j * 16 + li; return m < p.M ? m : p.M - 1; };
@@ -196,14 +220,20 @@ __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 
             for (int h2 = 0; h2 < 2; ++h2) {
                 int m = rowbase + j * 16 + h2 * 8 + (lane >> 3);
                 m = m < p.M ? m : p.M - 1;
-                hrows[h2] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(hsrc_r + (size_t)m * p.N));   // read once (proj +3-7 %, dfc2 +1-3 % with the residual / derivative loads non-temporal)
+                hring[j % HD_][h2] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(hsrc_r + (size_t)m * p.N));   // read once (proj +3-7 %, dfc2 +1-3 % with the residual / derivative loads non-temporal)
             }
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) hnext[i] = *reinterpret_cast<const bf16x4*>(hsrc + (size_t)hrow(j) * p.N + i * 16);
         }
     };
-    if (EPI == EPI_BF16_DGELU) hfetch(0);
+    if (EPI == EPI_BF16_DGELU) {
+        hfetch(0);
+        if constexpr (HROWS) {
+#pragma unroll
+            for (int d = 1; d < HD_; ++d) hfetch(d);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         bf16x4 hcur[4];
@@ -211,7 +241,7 @@ __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 
             if constexpr (HROWS) {
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2)
-                    *reinterpret_cast<u32x4*>(slab + SLAB_BYTES + (h2 * 8 + (lane >> 3)) * SLAB_STRIDE + (lane & 7) * 16) = hrows[h2];
+                    *reinterpret_cast<u32x4*>(slab + SLAB_BYTES + (h2 * 8 + (lane >> 3)) * SLAB_STRIDE + (lane & 7) * 16) = hring[j % HD_][h2];
                 wave_lds_sync();
 #pragma unroll
                 for (int i = 0; i < 4; ++i) hcur[i] = *reinterpret_cast<const bf16x4*>(slab + SLAB_BYTES + wr_off + i * 32);
@@ -219,7 +249,11 @@ __device__ __forceinline__ void tile_epilogue_128x64(const GemmParams& p, f32x4 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) hcur[i] = hnext[i];
             }
-            if (j + 1 < 8) hfetch(j + 1);
+            if constexpr (HROWS) {
+                if (j + HD_ < 8) hfetch(j + HD_);          // (slot j % HD_ has just been consumed)
+            } else {
+                if (j + 1 < 8) hfetch(j + 1);
+            }
         }
         const bool row_ok = rowbase + j * 16 + li < p.M;
 #pragma unroll

@@ -36,6 +36,26 @@
 #pragma once
 #include "gemm_tn4.h"
 
+// Diagnostic build only (tools/gemm_stamps.py compiles gemm.hip with -DP4P_T4P_STAMPS into its own library): s_memtime stamps of
+// every wave at the phase boundaries of every tile of the persistent loop, [workgroup][tile of the walk < 16][wave][6] u64 through a
+// device pointer set by p4p_debug_set_t4p_stamps.  No stamp in the product library.
+#ifdef P4P_T4P_STAMPS
+__device__ unsigned long long* g_t4p_stamps;
+extern "C" int p4p_debug_set_t4p_stamps(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_t4p_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : 2;
+}
+#define T4P_STAMP(k)                                                                                                   \
+    do {                                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        const unsigned long long ts_ = __builtin_readcyclecounter();                                                   \
+        if ((threadIdx.x & 63) == 0 && walk_i < 16)                                                                    \
+            g_t4p_stamps[(((size_t)blockIdx.x * 16 + walk_i) * 8 + (threadIdx.x >> 6)) * 6 + (k)] = ts_;               \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+    } while (0)
+#else
+#define T4P_STAMP(k) do { } while (0)
+#endif
+
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_tn4p_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[T4_SLOTS * T4_HT];
@@ -115,7 +135,17 @@ __global__ __launch_bounds__(512) void gemm_tn4p_kernel(GemmParams p) {
     // every XCD's run of tiles is whole bands of 8 row panels (gemm_tn.h: band_remap)
     const bool banded = p.band && tiles_n % 4 == 0 && tiles_n >= 8 && ntiles % 8 == 0 && (ntiles / 8) % (8 * tiles_n) == 0;
     bool fresh = true;                                     // the tile's first 7 half-tiles are not in flight yet
+    // Start-time shift (experiment, p4p_set_gemm_epilogue bits 8..: units of 1,024 cycles): every other workgroup of an XCD begins late,
+    // so that its epilogues -- HBM-bound when all 256 CUs store and load at once (tools/gemm_stamps.py: the proj epilogue takes 47k
+    // cycles on 256 CUs, 30k on 128) -- fall into the other half's K loops, which leave HBM idle.  The shift persists: the loop is persistent.
+    if ((p.epi_flags >> 8) && ((blockIdx.x >> 3) & 1)) {
+        const unsigned long long t0 = __builtin_readcyclecounter(), d = (unsigned long long)(p.epi_flags >> 8) * 1024;
+        while (__builtin_readcyclecounter() - t0 < d) __builtin_amdgcn_s_sleep(32);
+    }
+    int walk_i = -1;                                       // (stamps only)
     for (int it = blockIdx.x; it < ntiles; it += gridDim.x) {
+        ++walk_i;
+        T4P_STAMP(0);
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
         rin = lane >> 3; chunk = (lane & 7) ^ rin; li = lane & 15; g = lane >> 4;
         fo0 = li * 128 + ((g ^ (li & 7)) << 4); fo1 = fo0 ^ 64;
@@ -182,19 +212,27 @@ __global__ __launch_bounds__(512) void gemm_tn4p_kernel(GemmParams p) {
         if (wm == 1) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
 
+        T4P_STAMP(1);
         for (int u = 0; u < nk; u += 2) {
             T4P_KTILE(f.b0x, f.b0y)
             ++u;
             T4P_KTILE(f.b0y, f.b0x)
             --u;
         }
+        T4P_STAMP(2);
         if (wm == 0) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        T4P_STAMP(3);
+        // epilogues that LOAD (fp32 residual, gelu'): the seam's 14 LDS-DMAs, issued during the last two K-tiles, are waited for here:
+        // with one of them outstanding hipcc waits vmcnt(0)-like for every plain load of the epilogue (it does not count across a
+        // DMA), which serialised the residual prefetch against its own stores -- 45k of an 80k-cycle proj tile (tools/gemm_stamps.py)
+        if (EPI == EPI_F32_RESID || EPI == EPI_BF16_DGELU) WAIT_VM(0);
         {
             const int sl = slot_of(c_slot, 7 + wave / 3);      // the three slots no staged half-tile occupies
-            tile_epilogue_128x64<EPI, true>(p, acc, lds + sl * T4_HT + (wave % 3) * 4608, tm, m0, n0, wm, wn, wave, lane, bias4);
+            tile_epilogue_128x64<EPI, true, false>(p, acc, lds + sl * T4_HT + (wave % 3) * 4608, tm, m0, n0, wm, wn, wave, lane, bias4);
         }
         __builtin_amdgcn_sched_barrier(0);
+        T4P_STAMP(4);
         if (seam) {
             WAIT_VM(6);                                    // file header: the first four half-tiles have landed under either ordering model
         } else {
@@ -202,6 +240,7 @@ __global__ __launch_bounds__(512) void gemm_tn4p_kernel(GemmParams p) {
             st_slot = c_slot;
         }
         __builtin_amdgcn_sched_barrier(0);
+        T4P_STAMP(5);
         fresh = !seam;
 #undef T4P_STAGE
     }
