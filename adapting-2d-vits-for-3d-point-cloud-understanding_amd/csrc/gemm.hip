@@ -211,6 +211,12 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
                 if ((g_tn4_persistent & 1) && pg > 0 && tiles >= 2 * pg && p.K % 128 == 0 && p.K >= 256 && p.K <= 2304) {
                     GemmParams pb = p;
                     pb.band = (g_tn4_persistent & 2) ? 0 : 1;
+                    // start-time shift of every other workgroup of an XCD (gemm_tn4p.h), in 1,024-cycle units: the epilogues that are
+                    // HBM-bound when all CUs run them at once fall into the other half's K loops.  Same-box sweep (tools/gemm_shift_ab.py,
+                    // bit-identical outputs; M = 65,792 / 131,328): fp32 residual 124.9 -> 119.8 / 229.1 -> 216.9 us at 16k, dGELU
+                    // 325.4 -> 315.1 / 626 -> 617-620 at 8k, plain bf16 204.7 -> 199.4 / 397.5 -> 377.5 at 8k, GELU (VALU-bound) none
+                    if (!(pb.epi_flags >> 8) && !(pb.epi_flags & 2))
+                        pb.epi_flags |= (EPI == EPI_F32_RESID ? 16 : (EPI == EPI_BF16 || EPI == EPI_BF16_DGELU) ? 8 : 0) << 8;
                     hipLaunchKernelGGL((gemm_tn4p_kernel<EPI>), dim3(pg), dim3(512), 0, st, pb);
                     P4P_LAUNCH_CHECK();
                     return 0;

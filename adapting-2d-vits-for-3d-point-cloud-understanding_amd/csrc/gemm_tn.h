@@ -28,7 +28,7 @@ struct GemmParams {
     int M, N, K, group;
     int ldk;               // row stride of A and W in elements (= K, except for the split-K launches of gemm_tn2_kernel)
     int band;              // gemm_tn4p_kernel: banded tile order for wide outputs (band_remap); 0 = plain XCD-contiguous order
-    int epi_flags;         // experiment switch (p4p_set_gemm_epilogue): bit 0 = the residual / gelu' loads of the epilogues as hipcc counts them (no hand-counted prefetch)
+    int epi_flags;         // p4p_set_gemm_epilogue: bit 1 = no start-time shift of the persistent kernel; bits 8.. = that shift in 1,024-cycle units
 };
 
 enum {
