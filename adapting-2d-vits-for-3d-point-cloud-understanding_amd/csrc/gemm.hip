@@ -208,7 +208,7 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
                 // several tiles per CU and an even number (>= 4) of K-tiles: the persistent loop of gemm_tn4p.h hides the per-tile
                 // dispatch + pipeline-fill latency behind the previous tile's epilogue
                 const int pg = p4p_persistent_grid();       // CUs - reserved (capi.cpp); 0: a workgroup per tile
-                if ((g_tn4_persistent & 1) && pg > 0 && tiles >= 2 * pg && p.K % 128 == 0 && p.K >= 256 && p.K <= 2304) {
+                if ((g_tn4_persistent & 1) && pg > 0 && tiles >= 2 * pg && p.K % 128 == 0 && p.K >= 256 && p.K <= ((g_tn4_persistent & 4) ? 4096 : 2304)) {      // bit 2 (experiment): long K too
                     GemmParams pb = p;
                     pb.band = (g_tn4_persistent & 2) ? 0 : 1;
                     // start-time shift of every other workgroup of an XCD (gemm_tn4p.h), in 1,024-cycle units: the epilogues that are
@@ -452,6 +452,9 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
     *reinterpret_cast<f32x4*>(out + e) = s;
 }
 
+// (Round 4, measured and not kept: the slab sum with 8 floats per thread, every load of a thread issued up front, non-temporal loads:
+// wgrad + sum 277.8 -> 291.4 us (fc1), 275.1 -> 294.4 (fc2), qkv / proj unchanged -- the slabs have just been written and are read back
+// from L2 / Infinity Cache, which the streaming hint gives up.)
 // out[e] = sum_s slabs[s][e] in the fixed order s = 0, 1, ..: the positional-embedding gradient as the sum of the L block-input
 // gradients the encoder backward leaves in L slabs (functional._EncoderFn.backward), one pass instead of a read-modify-write per block
 extern "C" int p4p_sum_slabs_f32(const float* slabs, float* out, long long n, int nslabs, void* stream) {
@@ -466,7 +469,7 @@ extern "C" int p4p_sum_slabs_f32(const float* slabs, float* out, long long n, in
 static bool wgrad_use_v3(int M, int N, int K) { return N % W3_BN == 0 && K % W3_BK == 0 && M >= 4096; }
 static int g_wgrad_wide = 2;      // 0: 256x128 tiles, 1: 256x256, 2: 256x256 with the hand-interleaved issue order
 extern "C" int p4p_set_wgrad_wide(int v) { int o = g_wgrad_wide; g_wgrad_wide = v; return o; }
-static bool wgrad3_wide(int K) { return g_wgrad_wide && K % 256 == 0; }      // 256x256 tile, 8 waves, 1 workgroup per CU
+static bool wgrad3_wide(int K) { return (g_wgrad_wide & 3) && K % 256 == 0; }      // 256x256 tile, 8 waves, 1 workgroup per CU
 static int wgrad3_steps_per_split(int M, int N, int K) {
     // one round of workgroups: as many M-splits as the resident slots allow -- the CUs p4p_set_reserved_cus() leaves (capi.cpp):
     // with r CUs held by another kernel a grid of 256 would run 256 - r workgroups and then r more, i.e. take twice as long
@@ -509,7 +512,7 @@ extern "C" int p4p_gemm_wgrad_bf16(const void* G, const void* A, float* dW, floa
         int splits3 = ceil_div(ceil_div(M, 32), q.steps_per_split);
         q.out = workspace;
         const bool prof = p4p_prof_begin(1, 2.0 * M * N * K, st);
-        if (wgrad3_wide(K) && g_wgrad_wide == 2)
+        if (wgrad3_wide(K) && (g_wgrad_wide & 3) == 2)
             hipLaunchKernelGGL((gemm_wgrad3_kernel<256, true>), dim3((N / W3_BN) * (K / 256) * splits3), dim3(512), 0, st, q);
         else if (wgrad3_wide(K))
             hipLaunchKernelGGL(gemm_wgrad3_kernel<256>, dim3((N / W3_BN) * (K / 256) * splits3), dim3(512), 0, st, q);

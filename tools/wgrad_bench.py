@@ -15,7 +15,7 @@ for name, (n, k) in shapes.items():
     dw = torch.empty(n, k, device='cuda')
     res, ref = {}, None
     for rnd in range(3):
-        for v in (1, 2):
+        for v in (1, 2):                  # 256x256 tile without / with the hand-interleaved issue order
             lib.p4p_set_wgrad_wide(v)
             ops.gemm_wgrad(G, A, out=dw); torch.cuda.synchronize()
             if rnd == 0:
@@ -26,5 +26,5 @@ for name, (n, k) in shapes.items():
             for _ in range(10): ops.gemm_wgrad(G, A, out=dw)
             e.record(); torch.cuda.synchronize()
             res.setdefault(v, []).append(s.elapsed_time(e) / 10 * 1e-3)
-    print(name, {v: round(2 * M * n * k / min(t) * 1e-12) for v, t in res.items()}, flush=True)
+    print(name, {v: (round(2 * M * n * k / min(t) * 1e-12), f'{min(t) * 1e6:.1f} us') for v, t in res.items()}, '(main kernel + slab sum)', flush=True)
 lib.p4p_set_wgrad_wide(2)
