@@ -1207,6 +1207,7 @@ __global__ __launch_bounds__(RES_DKDV_NW * 64, 2) void attn_bwd_dkdv_res_kernel(
 #include "attention_lone.h"
 #include "attention_fused.h"
 #include "attention_fused2.h"
+#include "attention_fwd2.h"
 
 // experiment switch for tools/attn_ab.py (in-process A/B, default 0 = automatic): bit 0 = no resident forward / dQ,
 // bit 1 = no resident dK/dV, bit 2 = no two-pass (64 n + 1) forward, bit 3 = no fused backward, bit 5 = no start shift of the
@@ -1214,6 +1215,10 @@ __global__ __launch_bounds__(RES_DKDV_NW * 64, 2) void attn_bwd_dkdv_res_kernel(
 // bits 8-9 = start-shift phases - 1 and bits 10.. = shift in 1024-cycle units (sweeps).  Nothing in the product path sets it.
 static int g_attn_variant = 0;
 extern "C" int p4p_set_attention_variant(int v) { int o = g_attn_variant; g_attn_variant = v; return o; }
+// forward-only switch (tools/attn_fwd2_ab.py): bit 0 = the K/V-resident forward at T = 513 (attention_fwd2.h: measured 380-390 us against the
+// 360 us of attn_fwd_q_kernel<2>, NOTES.md A.6 -- not the default), bit 1 = a workgroup per pair instead of the walk, bit 2 = no start shift
+static int g_attn_fwd_variant = 0;
+extern "C" int p4p_set_attention_fwd_variant(int v) { int o = g_attn_fwd_variant; g_attn_fwd_variant = v; return o; }
 
 static int check_attn(const char* fn, int B, int T, int H, int D) {
     P4P_CHECK(B >= 1 && T >= 1 && H >= 1, "%s: bad sizes B=%d T=%d H=%d", fn, B, T, H);
@@ -1240,7 +1245,14 @@ extern "C" int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B,
         }
     } else if (T <= RES_ROWS - 31 && T >= 64 && !no_res)
         hipLaunchKernelGGL(attn_fwd_res_kernel, dim3(B * H), dim3(RES_NW * 64), 0, (hipStream_t)stream, p);
-    else {
+    else if (T == 513 && (g_attn_fwd_variant & 1)) {                        // K and V of the sequence resident: attention_fwd2.h
+        const int pg = p4p_persistent_grid();
+        if (pg > 0 && B * H > pg && !(g_attn_fwd_variant & 2)) {
+            if (!(g_attn_fwd_variant & 4)) { p.stagger_n = pg; p.stagger_phases = 3; p.stagger_cycles = 6 * 1024; }
+            hipLaunchKernelGGL((attn_fwd_kv_kernel<16, true>), dim3(pg), dim3(512), 0, (hipStream_t)stream, p);
+        } else
+            hipLaunchKernelGGL((attn_fwd_kv_kernel<16, false>), dim3(B * H), dim3(512), 0, (hipStream_t)stream, p);
+    } else {
         // measured at B=256, H=12 (tools/attn_ab.py): T=513: 542 / 499 / 533 us for 1 / 2 / 4 tiles per wave; T=2049: 5398 / 4643 / 4501
         const int qt = T >= 1024 ? 4 : 2;
         if (qt == 2 && T > 128)

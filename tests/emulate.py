@@ -154,6 +154,23 @@ def attention_lone_mode(T):
     return 'two_pass' if (T % 64 == 1 and 65 <= T <= 257) else 'online'
 
 
+def _attention_online32(s, v, c):
+    """csrc/attention_fwd2.h (T = 513).  Rows 0 .. T-2: ONE online chain over the 17 key tiles of 32 in ascending order (the last tile
+    holds key T-1 alone).  The last row: eight chains, wave w over key tiles 2 w, 2 w + 1 (wave 7: also the last tile), their
+    (max, sum, accumulator) triples combined in wave order."""
+    T = s.shape[-1]
+    TL = T - 1
+    groups = [list(range(k0, min(k0 + 32, T))) for k0 in range(0, T, 32)]
+    _, lsum, o = _online_chain(s[:, :, :TL], v, c, groups)
+    main = o * (1.0 / lsum)
+    sl = s[:, :, TL:]
+    parts = [_online_chain(sl, v, c, groups[2 * w:2 * w + 2] + ([groups[-1]] if w == 7 else [])) for w in range(8)]
+    M = torch.stack([m for m, _, _ in parts], 0).max(0).values
+    l = sum(lw * torch.exp2(m - M) for m, lw, _ in parts)
+    ol = sum(ow * torch.exp2(m - M) for m, _, ow in parts)
+    return torch.cat([main, ol * (1.0 / l)], dim=2)
+
+
 def _attention_two_pass(s, v, c):
     """csrc/attention_lone.h.  s [B,H,T,T] scores, v [B,H,T,hd]; returns the unrounded output [B,H,T,hd].
     Main query rows (all but the last): exact row maximum over ALL keys, numerators rounded to bf16 for the P.V product
@@ -200,21 +217,24 @@ def _online_chain(s, v, c, key_groups, m=None, lsum=None, o=None):
     return m, lsum, o
 
 
-def attention_emulated(qkv, B, T, H, round_output=True):
+def attention_emulated(qkv, B, T, H, round_output=True, mode=None):
     """qkv [B*T, 3*H*64] (bf16-valued fp32) -> attention output [B*T, H*64].  Two contracts, chosen as the library
     chooses its kernel (attention_lone_mode):
     'online'  (csrc/attention.hip: attn_fwd_tile): online softmax over 64-key tiles in ascending order: running maximum m
               in the base-2 domain c*s, numerators p = exp2(c*s - m) ROUNDED TO bf16 for the P.V product and for the denominator
               alike, accumulator rescaled by exp2(m_old - m_new) per tile, one division at the end;
-    'two_pass' (csrc/attention_lone.h): see _attention_two_pass.
+    'two_pass' (csrc/attention_lone.h): see _attention_two_pass;
+    'online32' (csrc/attention_fwd2.h, T = 513): see _attention_online32.
     The result is rounded to bf16 (round_output=False: the fp32 value in front of that rounding)."""
     hd = 64
     c = float(torch.tensor(hd ** -0.5, dtype=torch.float32) * torch.tensor(LOG2E, dtype=torch.float32))
     q, k, v = qkv.view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)          # [B,H,T,hd] each
     s = q @ k.transpose(-1, -2)                                        # [B,H,T,T] fp32 (exact bf16 products)
-    mode = attention_lone_mode(T)
+    mode = mode or attention_lone_mode(T)                              # 'online32': p4p_set_attention_fwd_variant(1), T = 513
     if mode == 'two_pass':
         out = _attention_two_pass(s, v, c)
+    elif mode == 'online32':
+        out = _attention_online32(s, v, c)
     else:
         _, lsum, o = _online_chain(s, v, c, [list(range(k0, min(k0 + KEY_TILE, T))) for k0 in range(0, T, KEY_TILE)])
         out = o * (1.0 / lsum)

@@ -564,6 +564,65 @@ def test_attention_backward_fused_t513_against_the_kernels_it_replaces(B, H):
         assert (new[sl].float() - qr.grad).abs().max().item() <= 3e-2 * sc
 
 
+@pytest.mark.parametrize('B,H', [(1, 1), (2, 12), (23, 12), (50, 6)])
+def test_attention_forward_kv_resident_t513(B, H):
+    """Round 4, not the default path (p4p_set_attention_fwd_variant(1)): attn_fwd_kv_kernel (T = 513: K and V of the sequence resident in LDS, 32-key tiles, the query on the lane) against its
+    rounding-matched statement (tests/emulate.py 'online32': per-element, a correct bf16 rounding up to flipped numerators), against
+    fp32 softmax attention, and lse2 against the exact log-sum-exp; the walk (pairs > CUs) bitwise equal to a workgroup per pair;
+    the streaming kernel it replaces (another tile order) agrees within bf16 rounding of the output."""
+    from p4p_amd import _lib
+    from tests import emulate as E
+    lib = _lib.lib()
+    T, D = 513, 64 * H
+    g = torch.Generator().manual_seed(77 + 3 * B + H)
+    qkv = (torch.randn(B * T, 3 * D, generator=g) * 1.5).to(torch.bfloat16).to(DEV)
+    old, old_lse = ops.attention_fwd(qkv, B, T, H)
+    old, old_lse = old.clone(), old_lse.clone()
+    try:
+        lib.p4p_set_attention_fwd_variant(1)
+        _kv_resident_checks(lib, qkv, old, old_lse, B, T, H, D)
+    finally:
+        lib.p4p_set_attention_fwd_variant(0)
+
+
+def _kv_resident_checks(lib, qkv, old, old_lse, B, T, H, D):
+    from tests import emulate as E
+    out, lse = ops.attention_fwd(qkv, B, T, H)
+    out, lse = out.clone(), lse.clone()
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
+    lib.p4p_set_attention_fwd_variant(1 | 2)
+    pp, pp_lse = ops.attention_fwd(qkv, B, T, H)
+    assert torch.equal(pp, out) and torch.equal(pp_lse, lse)
+    lib.p4p_set_attention_fwd_variant(1)
+    for _ in range(2):
+        again, again_lse = ops.attention_fwd(qkv, B, T, H)
+        assert torch.equal(again, out) and torch.equal(again_lse, lse)
+    assert (old.float() - out.float()).abs().max().item() <= 2e-2
+    assert (old_lse - lse).abs().max().item() <= 2e-2
+    nb = min(B, 2)
+    with torch.no_grad():
+        for b0 in (0, B - nb):
+            sl = slice(b0 * T, (b0 + nb) * T)
+            q = qkv[sl].float()
+            torch.testing.assert_close(out[sl].float(), _attn_ref(q, nb, T, H), rtol=2e-2, atol=2e-2)
+            assert E.link_stats(out[sl], E.attention_emulated(q, nb, T, H, round_output=False, mode='online32'), 'att',
+                                E.attention_flip_unit(qkv[sl], nb, T, H)) <= E.LINK_LIMITS['att']
+            qq, kk, _ = q.view(nb, T, 3, H, 64).permute(2, 0, 3, 1, 4)
+            s = (qq.double() @ kk.double().transpose(-1, -2)) * (64 ** -0.5)
+            want = torch.logsumexp(s, -1) * 1.4426950408889634          # lse2: base-2 domain
+            assert (lse[b0:b0 + nb].double() - want).abs().max().item() <= 5e-3
+        # the rescale: one key dominates late in the sequence (and for the odd query: in another wave's share)
+        spike = qkv.clone().view(B, T, 3, H, 64)
+        spike[:, T - 1, 1] = spike[:, 0, 0] * 4
+        spike[:, 300, 1] = spike[:, T - 1, 0] * 4
+        spike = spike.view(B * T, 3 * D).contiguous()
+        out2, _ = ops.attention_fwd(spike, B, T, H)
+        sl = slice(0, nb * T)
+        torch.testing.assert_close(out2[sl].float(), _attn_ref(spike[sl].float(), nb, T, H), rtol=2e-2, atol=2e-2)
+        assert E.link_stats(out2[sl], E.attention_emulated(spike[sl].float(), nb, T, H, round_output=False, mode='online32'), 'att',
+                            E.attention_flip_unit(spike[sl], nb, T, H)) <= E.LINK_LIMITS['att']
+
+
 @pytest.mark.parametrize('B,H', [(43, 6), (25, 12), (300, 1), (23, 12)])
 def test_attention_backward_persistent_walk_equals_a_workgroup_per_pair(B, H):
     """T = 257 with more (batch, head) pairs than CUs: one workgroup per CU WALKS its pairs (the default).  Bit for bit what a
