@@ -38,6 +38,12 @@
         __syncthreads();                       \
     } while (0)
 
+// Lazy rescale of the online-softmax forward kernels (the flash-attention idiom): the reference m of a 16-query tile follows the running row
+// maximum only when some query of the tile outgrew it by more than 2^ATT_LAZY_THR; numerators then reach 2^thr instead of 1 -- the same
+// relative rounding in bf16, the same quotient o / l -- and the rescale of the accumulators (with 16 queries deciding together it ran on
+// nearly every tile of random data: 20 multiplies per 16 scores of a lane) becomes rare.  Measured (tools/attn_fwd_thr_ab.py, same box):
+// T = 513 363 -> 341 us, T = 2049 (B = 8, H = 16) 211 -> 190 us.  tests/emulate.py states it (ONLINE_THR).
+#define ATT_LAZY_THR 4.0f
 struct AttnParams {
     const __bf16* qkv;     // [B*T, 3D]
     const __bf16* o;       // [B*T, D]   (bwd)
@@ -49,6 +55,7 @@ struct AttnParams {
     int B, T, H, D;
     float scale;
     int stagger_n, stagger_phases, stagger_cycles;   // attention_fused.h: start-time shift of the first round of workgroups (0 = off)
+    float thr;             // fwd, online-softmax kernels: lazy-rescale threshold in base-2 exponent units (ATT_LAZY_THR; 0 = the running maximum exactly)
 };
 
 // Workgroup -> (64-row block, head, sequence).  The hardware deals consecutive workgroups round-robin to the 8 XCDs
@@ -189,7 +196,7 @@ __device__ __forceinline__ float xor_lanes_sum(float v) { return quad_rows_sum(v
 // The accumulators are rescaled only when some lane's maximum grew (wave-uniform branch; alpha = 1 exactly otherwise).
 template <bool MASK>
 __device__ __forceinline__ void attn_fwd_tile(const char* kt_lds, const char* vt_lds, const bf16x8 (&qf)[2], f32x4 (&o)[4],
-                                              float& m, f32x4& lacc, float c, int key0, int T, int lane) {
+                                              float& m, f32x4& lacc, float c, float thr, int key0, int T, int lane) {
     const int g = lane >> 4;
     const int nvalid = MASK ? T - key0 : 64;            // valid keys in this tile (wave-uniform)
     f32x4 s[4];
@@ -213,7 +220,7 @@ __device__ __forceinline__ void attn_fwd_tile(const char* kt_lds, const char* vt
 #pragma unroll
     for (int k16 = 1; k16 < 4; ++k16) mx = fmaxf(mx, fmaxf(fmaxf(s[k16][0], s[k16][1]), fmaxf(s[k16][2], s[k16][3])));
     mx = xor_lanes_max(mx) * c;
-    if (__builtin_amdgcn_ballot_w64(mx > m) != 0) {
+    if (__builtin_amdgcn_ballot_w64(mx > m + thr) != 0) {     // lazy rescale: below
         const float mnew = fmaxf(m, mx);
         const float alpha = __builtin_amdgcn_exp2f(m - mnew);
         m = mnew;
@@ -297,12 +304,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
         STAGE_FENCE();
         const char* cur = lds + (kt & 1) * 2 * TILE_BYTES;
         if (kt + 1 < nkt) stage_any(kt + 1, lds + ((kt + 1) & 1) * 2 * TILE_BYTES);
-        if (wave_active) attn_fwd_tile<false>(cur, cur + TILE_BYTES, qf, o, m, lacc, c, kt * 64, T, lane);
+        if (wave_active) attn_fwd_tile<false>(cur, cur + TILE_BYTES, qf, o, m, lacc, c, p.thr, kt * 64, T, lane);
     }
     if (nfull < nkt) {
         STAGE_FENCE();
         const char* cur = lds + (nfull & 1) * 2 * TILE_BYTES;
-        if (wave_active) attn_fwd_tile<true>(cur, cur + TILE_BYTES, qf, o, m, lacc, c, nfull * 64, T, lane);
+        if (wave_active) attn_fwd_tile<true>(cur, cur + TILE_BYTES, qf, o, m, lacc, c, p.thr, nfull * 64, T, lane);
     }
     const float l = lacc[0];
     const float inv = 1.0f / l;
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_kernel(AttnParams p) 
 // as the matrix pipe.  With QT tiles per wave every K / V fragment read feeds QT MFMAs: LDS bytes per FLOP drop by QT.
 template <bool MASK, int QT>
 __device__ __forceinline__ void attn_fwd_tile_q(const char* kt_lds, const char* vt_lds, const bf16x8 (&qf)[QT][2],
-                                                f32x4 (&o)[QT][4], float (&m)[QT], f32x4 (&lacc)[QT], float c, int key0, int T,
+                                                f32x4 (&o)[QT][4], float (&m)[QT], f32x4 (&lacc)[QT], float c, float thr, int key0, int T,
                                                 int lane) {
     const int g = lane >> 4;
     const int nvalid = MASK ? T - key0 : 64;
@@ -355,7 +362,7 @@ __device__ __forceinline__ void attn_fwd_tile_q(const char* kt_lds, const char* 
         for (int k16 = 1; k16 < 4; ++k16)
             mx = fmaxf(mx, fmaxf(fmaxf(s[t][k16][0], s[t][k16][1]), fmaxf(s[t][k16][2], s[t][k16][3])));
         mx = xor_lanes_max(mx) * c;
-        if (__builtin_amdgcn_ballot_w64(mx > m[t]) != 0) {       // some lane's maximum grew: rescale (see attn_fwd_tile)
+        if (__builtin_amdgcn_ballot_w64(mx > m[t] + thr) != 0) {       // some lane's maximum grew (by more than thr: lazy rescale, 0 = off): rescale (see attn_fwd_tile)
             const float mnew = fmaxf(m[t], mx);
             const float alpha = __builtin_amdgcn_exp2f(m[t] - mnew);
             m[t] = mnew;
@@ -464,7 +471,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_q_kernel(AttnParams p
 #endif
         const char* cur = lds + (kt & 1) * 2 * TILE_BYTES;
         if (kt + 1 < nkt) stage_any(kt + 1, lds + ((kt + 1) & 1) * 2 * TILE_BYTES);
-        if (wave_active) attn_fwd_tile_q<false, QT>(cur, cur + TILE_BYTES, qf, o, m, lacc, c, kt * 64, T, lane);
+        if (wave_active) attn_fwd_tile_q<false, QT>(cur, cur + TILE_BYTES, qf, o, m, lacc, c, p.thr, kt * 64, T, lane);
 #ifdef P4P_LONE_STAMPS
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long tc = __builtin_readcyclecounter();
@@ -482,7 +489,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_fwd_q_kernel(AttnParams p
     if (nfull < nkt) {
         STAGE_FENCE();
         const char* cur = lds + (nfull & 1) * 2 * TILE_BYTES;
-        if (wave_active) attn_fwd_tile_q<true, QT>(cur, cur + TILE_BYTES, qf, o, m, lacc, c, nfull * 64, T, lane);
+        if (wave_active) attn_fwd_tile_q<true, QT>(cur, cur + TILE_BYTES, qf, o, m, lacc, c, p.thr, nfull * 64, T, lane);
     }
 #pragma unroll
     for (int tq = 0; tq < QT; ++tq) {
@@ -559,9 +566,9 @@ __global__ __launch_bounds__(RES_NW * 64, 4) void attn_fwd_res_kernel(AttnParams
         float m = -INFINITY;
         f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
         for (int kt = 0; kt < nfull; ++kt)
-            attn_fwd_tile<false>(klds + kt * TILE_BYTES, vlds + kt * TILE_BYTES, qf[s], o, m, lacc, c, kt * 64, T, lane);
+            attn_fwd_tile<false>(klds + kt * TILE_BYTES, vlds + kt * TILE_BYTES, qf[s], o, m, lacc, c, p.thr, kt * 64, T, lane);
         if (nfull < nkt)
-            attn_fwd_tile<true>(klds + nfull * TILE_BYTES, vlds + nfull * TILE_BYTES, qf[s], o, m, lacc, c, nfull * 64, T, lane);
+            attn_fwd_tile<true>(klds + nfull * TILE_BYTES, vlds + nfull * TILE_BYTES, qf[s], o, m, lacc, c, p.thr, nfull * 64, T, lane);
         const float l = lacc[0];
         const float inv = 1.0f / l;
         const int q = qt * 16 + i;
@@ -1215,7 +1222,7 @@ __global__ __launch_bounds__(RES_DKDV_NW * 64, 2) void attn_bwd_dkdv_res_kernel(
 // bits 8-9 = start-shift phases - 1 and bits 10.. = shift in 1024-cycle units (sweeps).  Nothing in the product path sets it.
 static int g_attn_variant = 0;
 extern "C" int p4p_set_attention_variant(int v) { int o = g_attn_variant; g_attn_variant = v; return o; }
-// forward-only switch (tools/attn_fwd2_ab.py): bit 0 = the K/V-resident forward at T = 513 (attention_fwd2.h: measured 380-390 us against the
+// forward-only switch (tools/attn_fwd2_ab.py, tools/attn_fwd_thr_ab.py): bit 3 = exact running maximum (no lazy rescale) in the online kernels; bit 0 = the K/V-resident forward at T = 513 (attention_fwd2.h: measured 380-390 us against the
 // 360 us of attn_fwd_q_kernel<2>, NOTES.md A.6 -- not the default), bit 1 = a workgroup per pair instead of the walk, bit 2 = no start shift
 static int g_attn_fwd_variant = 0;
 extern "C" int p4p_set_attention_fwd_variant(int v) { int o = g_attn_fwd_variant; g_attn_fwd_variant = v; return o; }
@@ -1235,6 +1242,7 @@ extern "C" int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B,
     p.qkv = (const __bf16*)qkv; p.out = (__bf16*)out; p.lse2 = lse2; p.B = B; p.T = T; p.H = H; p.D = D; p.scale = scale;
     const bool prof = p4p_prof_begin(3, 4.0 * B * H * (double)T * T * HD, (hipStream_t)stream);      // bench.py: attention forward
     const bool no_res = g_attn_variant & 1, no_lone = g_attn_variant & 4;
+    p.thr = (g_attn_fwd_variant & 8) ? 0.0f : ATT_LAZY_THR;
     if (T % 64 == 1 && T >= 65 && T <= 257 && !no_lone) {                    // 64 n + 1 rows: attention_lone.h
         const dim3 grid(B * H), block(LONE_NW * 64);
         switch ((T - 1) / 64) {

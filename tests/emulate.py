@@ -136,6 +136,7 @@ def p3embed_emulated(points, idx, params, k, eps=1e-5, running=None, tape=None):
 # ------------------------------------------------------------------------------------------------
 LOG2E = 1.4426950408889634
 KEY_TILE = 64            # csrc/attention.hip: keys are consumed in tiles of 64 rows, ascending
+ONLINE_THR = 4.0         # csrc/attention.hip: ATT_LAZY_THR -- the reference m of a 16-query tile moves only when a query outgrew it by more than 2^4
 
 
 def _exp2_fma(s, c, m):
@@ -154,17 +155,21 @@ def attention_lone_mode(T):
     return 'two_pass' if (T % 64 == 1 and 65 <= T <= 257) else 'online'
 
 
+ONLINE32_THR = 4.0        # csrc/attention_fwd2.h: FW2_THR
+
+
 def _attention_online32(s, v, c):
     """csrc/attention_fwd2.h (T = 513).  Rows 0 .. T-2: ONE online chain over the 17 key tiles of 32 in ascending order (the last tile
     holds key T-1 alone).  The last row: eight chains, wave w over key tiles 2 w, 2 w + 1 (wave 7: also the last tile), their
-    (max, sum, accumulator) triples combined in wave order."""
+    (max, sum, accumulator) triples combined in wave order.  The reference m of a chain moves to the row maximum only when some query of
+    its 32-row tile outgrew it by more than 2^ONLINE32_THR (numerators up to 2^thr; _online_chain)."""
     T = s.shape[-1]
     TL = T - 1
     groups = [list(range(k0, min(k0 + 32, T))) for k0 in range(0, T, 32)]
-    _, lsum, o = _online_chain(s[:, :, :TL], v, c, groups)
+    _, lsum, o = _online_chain(s[:, :, :TL], v, c, groups, thr=ONLINE32_THR, rows=32)
     main = o * (1.0 / lsum)
     sl = s[:, :, TL:]
-    parts = [_online_chain(sl, v, c, groups[2 * w:2 * w + 2] + ([groups[-1]] if w == 7 else [])) for w in range(8)]
+    parts = [_online_chain(sl, v, c, groups[2 * w:2 * w + 2] + ([groups[-1]] if w == 7 else []), thr=ONLINE32_THR, rows=1) for w in range(8)]
     M = torch.stack([m for m, _, _ in parts], 0).max(0).values
     l = sum(lw * torch.exp2(m - M) for m, lw, _ in parts)
     ol = sum(ow * torch.exp2(m - M) for m, _, ow in parts)
@@ -196,11 +201,13 @@ def _attention_two_pass(s, v, c):
     return torch.cat([main, o * (1.0 / l)], dim=2)
 
 
-def _online_chain(s, v, c, key_groups, m=None, lsum=None, o=None):
+def _online_chain(s, v, c, key_groups, m=None, lsum=None, o=None, thr=None, rows=None):
     """One online-softmax chain over the given key groups (lists of key indices), attention.hip: attn_fwd_tile: running
     maximum, numerators rounded to bf16 for P.V AND for the denominator (round 3: the row sums come out of the matrix pipe, one MFMA
     against an all-ones operand, as in attention_lone.h), accumulator rescaled per group.  A group of ONE key
-    whose numerator is exactly 1 reproduces the 'last key first' start of attention_lone.h."""
+    whose numerator is exactly 1 reproduces the 'last key first' start of attention_lone.h.
+    thr / rows (attention_fwd2.h): the reference m moves to the running maximum only when some row of a block of `rows` consecutive query
+    rows outgrew it by more than thr; then for every row of the block."""
     B, H, R, _ = s.shape
     if m is None:
         m = torch.full((B, H, R, 1), float('-inf'), device=s.device)
@@ -208,8 +215,16 @@ def _online_chain(s, v, c, key_groups, m=None, lsum=None, o=None):
         o = torch.zeros(B, H, R, v.shape[-1], device=s.device)
     for keys in key_groups:
         st = s[..., keys]
-        mnew = torch.maximum(m, (st.max(-1, keepdim=True).values * c).detach())
+        mx = (st.max(-1, keepdim=True).values * c).detach()
+        mnew = torch.maximum(m, mx)
+        if thr is not None:
+            nb = -(-R // rows)
+            g = torch.zeros(B, H, nb * rows, 1, dtype=torch.bool, device=s.device)
+            g[:, :, :R] = mx > m + thr
+            grew = g.view(B, H, nb, rows).any(-1, keepdim=True).expand(B, H, nb, rows).reshape(B, H, nb * rows, 1)[:, :, :R]
+            mnew = torch.where(grew, mnew, m)
         alpha = torch.exp2(m - mnew)
+        alpha = torch.where(mnew == m, torch.ones_like(alpha), alpha)      # (-inf) - (-inf): no key seen yet, nothing to scale
         p = _exp2_fma(st, c, mnew)
         lsum = lsum * alpha + _r(p).sum(-1, keepdim=True)
         o = o * alpha + _r(p) @ v[:, :, keys]
@@ -220,9 +235,10 @@ def _online_chain(s, v, c, key_groups, m=None, lsum=None, o=None):
 def attention_emulated(qkv, B, T, H, round_output=True, mode=None):
     """qkv [B*T, 3*H*64] (bf16-valued fp32) -> attention output [B*T, H*64].  Two contracts, chosen as the library
     chooses its kernel (attention_lone_mode):
-    'online'  (csrc/attention.hip: attn_fwd_tile): online softmax over 64-key tiles in ascending order: running maximum m
-              in the base-2 domain c*s, numerators p = exp2(c*s - m) ROUNDED TO bf16 for the P.V product and for the denominator
-              alike, accumulator rescaled by exp2(m_old - m_new) per tile, one division at the end;
+    'online'  (csrc/attention.hip: attn_fwd_tile): online softmax over 64-key tiles in ascending order: reference m in the base-2
+              domain c*s (the running maximum, followed lazily: round 4, ONLINE_THR, decided per tile of 16 query rows), numerators
+              p = exp2(c*s - m) ROUNDED TO bf16 for the P.V product and for the denominator alike, accumulator rescaled by
+              exp2(m_old - m_new) when m moves, one division at the end;
     'two_pass' (csrc/attention_lone.h): see _attention_two_pass;
     'online32' (csrc/attention_fwd2.h, T = 513): see _attention_online32.
     The result is rounded to bf16 (round_output=False: the fp32 value in front of that rounding)."""
@@ -236,7 +252,8 @@ def attention_emulated(qkv, B, T, H, round_output=True, mode=None):
     elif mode == 'online32':
         out = _attention_online32(s, v, c)
     else:
-        _, lsum, o = _online_chain(s, v, c, [list(range(k0, min(k0 + KEY_TILE, T))) for k0 in range(0, T, KEY_TILE)])
+        _, lsum, o = _online_chain(s, v, c, [list(range(k0, min(k0 + KEY_TILE, T))) for k0 in range(0, T, KEY_TILE)],
+                                   thr=ONLINE_THR, rows=16)
         out = o * (1.0 / lsum)
     if round_output:
         out = _r(out)

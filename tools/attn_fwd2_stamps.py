@@ -11,6 +11,7 @@ subprocess.check_call(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '-sh
                        '-fno-honor-nans', '-fno-slp-vectorize', '-Wno-unused-value', '-Wno-pass-failed', '-DP4P_FW2_STAMPS', '-I', CS] + extra +
                       [os.path.join(CS, 'attention.hip'), '-x', 'hip', os.path.join(CS, 'capi.cpp'), '-o', so])
 lib = ctypes.CDLL(so)
+lib.p4p_set_attention_fwd_variant(1 | int(os.environ.get('FW2_VARIANT', '0')))
 B, T, H = int(os.environ.get('FW2_B', 256)), 513, int(os.environ.get('FW2_H', 12))
 D = 64 * H
 g = torch.Generator().manual_seed(0)
@@ -24,13 +25,12 @@ for _ in range(3):
 torch.cuda.synchronize()
 raw = lse[B * H * T:].view(torch.int64).view(B * H, 16).cpu().double()
 rel = raw - raw[:, 0:1]
-names = ['start', 'K / V DMAs issued, Q loads issued', 'images landed + barrier', '16 key tiles x 2 query tiles', 'last tile + outputs', 'odd query tiles',
-         'partials, barrier, combine (end)']
+names = ['top of the pair', 'odd query tiles of waves 0-3', 'key tiles of half 0 (steps 0 .. 14)', 'barrier E + DMAs of the next pair, half 0', 'key tiles of half 1 + drain',
+         'Q of the next pair, outputs, odd tiles of waves 4-7', 'barrier T, DMAs half 1, combine (end)']
 print(f'mean s_memtime ticks since the pair started (thread 0), over {B * H} pairs:')
 prev = 0.0
 for k, n in enumerate(names):
     m = float(rel[:, k].mean())
     print(f'  {n:36s} {m:10.0f}   (+{m - prev:8.0f})')
     prev = m
-print('end of the key-tile loop per wave (ticks since the pair started):', ' '.join(f'{float(rel[:, 8 + w].mean()):.0f}' for w in range(8)))
 print('kernel span', float(raw[:, 6].max() - raw[:, 0].min()), 'ticks (flags', ' '.join(extra), '); sum of pair lifetimes / 256 CUs', float(rel[:, 6].sum() / 256))
