@@ -51,7 +51,8 @@ def wgrad_case():
 
 def attn_case():
     """fp32 reference within bf16 noise (forward and gradients); against the rounding-matched statement every output within
-    half an ulp plus THREE numerators of its row rounded the other way (2^-9 p_max |v|_max each): the statement's own bound
+    half an ulp plus FOUR numerators of its row rounded the other way (2^-9 p_max |v|_max each; three before the lazy rescale of round 4, under
+    which the largest numerator of a row is no longer exactly 1: one of 282 cases reached 3.0 + 1e-4, tools/attn_lazy_flips.py): the statement's own bound
     (tests/emulate.py 'att') is a statistic of fixed seeds, a sweep needs the per-row form."""
     from tests import emulate as E
     B, H = int(rng.integers(1, 5)), int(rng.integers(1, 17))
@@ -70,7 +71,7 @@ def attn_case():
         q, k, v = qkv.float().view(B, Tn, 3, H, 64).permute(2, 0, 3, 1, 4)
         pmax = torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1).amax(-1)              # (B,H,T)
         vmax = v.abs().amax(2, keepdim=True)                                            # (B,H,1,64)
-        slack = (3 * 2.0 ** -9) * (pmax.unsqueeze(-1) * vmax).permute(0, 2, 1, 3).reshape(B * Tn, D)
+        slack = (4 * 2.0 ** -9) * (pmax.unsqueeze(-1) * vmax).permute(0, 2, 1, 3).reshape(B * Tn, D)
         excess = ((out.float() - emu).abs() - 0.5 * E.bf16_ulp(emu) - slack - 1e-6).max()
         assert float(excess) <= 0, ('attention vs statement', B, Tn, H, float(excess))
     dout = torch.randn(B * Tn, D, generator=g).to(torch.bfloat16).to(DEV)
