@@ -16,6 +16,9 @@ from . import ops
 # statement can be checked LINK BY LINK against the pipeline's own upstream tensors (tests/test_gpu_matched_parity.py)
 _CAPTURE = None
 _CAPTURE_BWD = None        # tests only: a dict that the encoder's backward fills with every block's upstream gradient
+_FREE_DSTACK_EARLY = False    # encoder backward: copy the returned block-input gradient out of the slab stack so that the stack is freed before the
+                              # embedding-stage backward.  Measured (tools/peak_memory.py): the step's peak is 29.0 GiB (N=1024) / 56.0 GiB (N=2048) of 288
+                              # either way -- it is set inside the encoder backward, where the stack must exist -- so the copy is off
 
 
 def _bf16_weights(w, want_t, col0=0, cols=None):
@@ -466,6 +469,11 @@ class _EncoderFn(torch.autograd.Function):
         if _CAPTURE_BWD is not None:
             _CAPTURE_BWD['encoder_din'] = dx.detach().clone()
         dpos = ops.sum_slabs(dstack) if L else torch.zeros(M, D, dtype=torch.float32, device=dev)
+        if L and _FREE_DSTACK_EARLY:
+            # the returned gradient would be a view of the stack and pin all L slabs (2.4 GB at N=1024 / B=256, 4.8 GB at N=2048) through the
+            # embedding-stage backward: one 202-MB copy (~70 us) lets the stack go here
+            dx = dx.clone()
+            del dstack
         return (dx.view(B, T, D), dpos.view(B, T, D), None, None, None, None, dnw, dnb, *grads)
 
 
