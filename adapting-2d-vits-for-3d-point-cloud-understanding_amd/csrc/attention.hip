@@ -1262,7 +1262,10 @@ extern "C" int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B,
             hipLaunchKernelGGL((attn_fwd_kv_kernel<16, false>), dim3(B * H), dim3(512), 0, (hipStream_t)stream, p);
     } else {
         // measured at B=256, H=12 (tools/attn_ab.py): T=513: 542 / 499 / 533 us for 1 / 2 / 4 tiles per wave; T=2049: 5398 / 4643 / 4501
-        const int qt = T >= 1024 ? 4 : 2;
+        // round 4, with the lazy rescale (tools/attn_fwd_thr_ab.py): T=513: 337 / 406 us for 2 / 4 tiles; T=2049, B=8, H=16 (128 pairs): 175.5 / 184.3 us --
+        // four tiles per wave pay only when their 256-row workgroups still fill the chip many times over (B=256: 4.50 against 4.64 ms)
+        const bool many = (long long)B * H * ceil_div(T, 256) >= 16ll * p4p_device_cu_count();
+        const int qt = (g_attn_fwd_variant & 48) ? ((g_attn_fwd_variant & 16) ? 4 : 2) : (T >= 1024 && many ? 4 : 2);     // bits 4 / 5: force 4 / 2 (A/B)
         if (qt == 2 && T > 128)
             hipLaunchKernelGGL(attn_fwd_q_kernel<2>, dim3((unsigned)(ceil_div((long long)B * H, 8) * 8 * ceil_div(T, 128))),
                                dim3(ATT_THREADS), 0, (hipStream_t)stream, p);

@@ -127,6 +127,7 @@ static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) 
 
 // persistent launches (capi.cpp): workgroups = CUs of the current device - p4p_set_reserved_cus(); 0 = no persistent kernels
 int p4p_persistent_grid(void);
+extern "C" int p4p_device_cu_count(void);
 
 // launch profiler (capi.cpp): brackets one kernel launch with HIP events when enabled for `kind`
 bool p4p_prof_begin(int kind, double flops, hipStream_t st);

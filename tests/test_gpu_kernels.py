@@ -564,6 +564,28 @@ def test_attention_backward_fused_t513_against_the_kernels_it_replaces(B, H):
         assert (new[sl].float() - qr.grad).abs().max().item() <= 3e-2 * sc
 
 
+@pytest.mark.parametrize('B,T,H', [(2, 2049, 3), (1, 1300, 2), (3, 513, 4)])
+def test_attention_forward_two_and_four_query_tiles_per_wave_are_bit_identical(B, T, H):
+    """attn_fwd_q_kernel<2> / <4>: the number of 16-query tiles a wave carries is a scheduling choice (round 4: taken by how many times the
+    256-row workgroups fill the chip) -- every query tile runs the same chain over the same key tiles."""
+    from p4p_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(T + B)
+    qkv = (torch.randn(B * T, 3 * 64 * H, generator=g) * 1.5).to(torch.bfloat16).to(DEV)
+    try:
+        lib.p4p_set_attention_fwd_variant(16)
+        o4, l4 = ops.attention_fwd(qkv, B, T, H)
+        o4, l4 = o4.clone(), l4.clone()
+        lib.p4p_set_attention_fwd_variant(32)
+        o2, l2 = ops.attention_fwd(qkv, B, T, H)
+        o2, l2 = o2.clone(), l2.clone()
+    finally:
+        lib.p4p_set_attention_fwd_variant(0)
+    od, ld = ops.attention_fwd(qkv, B, T, H)
+    assert torch.equal(o2, o4) and torch.equal(l2, l4)
+    assert torch.equal(od, o2) and torch.equal(ld, l2)
+
+
 @pytest.mark.parametrize('B,H', [(1, 1), (2, 12), (23, 12), (50, 6)])
 def test_attention_forward_kv_resident_t513(B, H):
     """Round 4, not the default path (p4p_set_attention_fwd_variant(1)): attn_fwd_kv_kernel (T = 513: K and V of the sequence resident in LDS, 32-key tiles, the query on the lane) against its

@@ -31,9 +31,9 @@ for (B, T, H, scale) in [(256, 513, 12, 1.0), (8, 2049, 16, 1.0), (256, 513, 12,
     qkv = (torch.randn(B * T, 3 * D, generator=g) * scale).to(torch.bfloat16).cuda()
     for rep in range(2):
         res = {}
-        for name, v in [('exact maximum', 8), ('lazy rescale 2^4', 0)]:
+        for name, v in [('exact maximum', 8), ('lazy rescale 2^4', 0), ('lazy, 4 tiles / wave', 16), ('lazy, 2 tiles / wave', 32)]:
             med, mn, out, lse = timed(qkv, B, T, H, v)
             res[name] = (out, lse)
-            print(f'B={B} T={T} H={H} x{scale} {name:18s} median {med:7.1f} us  min {mn:7.1f} us', flush=True)
+            print(f'B={B} T={T} H={H} x{scale} {name:22s} median {med:7.1f} us  min {mn:7.1f} us', flush=True)
     a, b = res['exact maximum'], res['lazy rescale 2^4']
     print('   max |out diff|', (a[0].float() - b[0].float()).abs().max().item(), ' lse diff', (a[1] - b[1]).abs().max().item())
