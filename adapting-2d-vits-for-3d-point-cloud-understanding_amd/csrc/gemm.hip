@@ -40,6 +40,10 @@ extern "C" int p4p_set_gemm_persistent(int v) { int o = g_tn4_persistent; g_tn4_
 extern "C" int p4p_set_gemm_variant(int v) { int o = g_gemm_variant; g_gemm_variant = v; return o; }
 static int g_epi_flags = 0;                 // A/B switch: bit 0 = epilogue loads as hipcc counts them (gemm_tn3.h: epi_resid_full off)
 extern "C" int p4p_set_gemm_epilogue(int v) { int o = g_epi_flags; g_epi_flags = v; return o; }
+static int g_peel_wide_rounds = 4;          // up to how many rounds of big tiles a WIDE output (> 4 tiles per row panel) has its tail row panel peeled.  Round 4 tried 32
+                                            // (tools/gemm_peel_ab.py, M = 65,792, isolated: qkv 213.6 -> 207.0 us, fc1 379.6 -> 362.6, dfc2 326.3 -> 317.4, bit-identical)
+                                            // and the whole step said no (tools/peel_step_ab.py, same box, interleaved: 50.43-50.49 ms whole, 50.64-50.75 peeled): 4 stays
+extern "C" int p4p_set_gemm_peel_rounds(int v) { int o = g_peel_wide_rounds; g_peel_wide_rounds = v; return o; }
 
 // ---- split-K for the short, wide tail launches (few workgroups, long K loop: latency-bound at one K-step per ~0.5 us)
 // out[m][n] = sum_s part[s][m][n] + bias[n] (+ resid[m][n]), fixed order; fp32 or bf16 output
@@ -140,7 +144,7 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
             const long long total = (long long)tiles_m * tiles_n;
             const long long rounds = total / slots, rem = total % slots;
             const int peel_max_rounds = 12;     // narrow N (<= 4 tiles per panel): measured at N=2048 (6 rounds + 3 tiles)
-            if (rounds >= 1 && rounds <= (tiles_n <= 4 ? peel_max_rounds : 4) && rem > 0 && rem * 8 <= slots && rem % tiles_n == 0 && rem / tiles_n < tiles_m) {
+            if (rounds >= 1 && rounds <= (tiles_n <= 4 ? peel_max_rounds : g_peel_wide_rounds) && rem > 0 && rem * 8 <= slots && rem % tiles_n == 0 && rem / tiles_n < tiles_m) {
                 GemmParams a = p, b = p;
                 a.M = (tiles_m - (int)(rem / tiles_n)) * 256;           // whole panels for the big-tile launch
                 const int peel = p.M - a.M;                             // rows handled by the small-tile launch

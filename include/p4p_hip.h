@@ -184,6 +184,7 @@ int p4p_set_gemm_variant(int v);
 int p4p_set_wgrad_wide(int v);
 int p4p_set_gemm_persistent(int v);        /* 1 (default): short-K GEMMs with several tiles per CU run the persistent tile loop (gemm_tn4p.h); 0: one workgroup per tile; 3: persistent without the banded tile order of wide outputs */
 int p4p_set_gemm_epilogue(int v);          /* bit 1: no start-time shift in the persistent GEMM; bits 8..: that shift in 1,024-cycle units (0 = the per-epilogue default); bit 0: unused */
+int p4p_set_gemm_peel_rounds(int v);       /* wide outputs (> 4 tiles of 256 columns): peel the tail row panel(s) into a small-tile launch when the big tiles run at most v rounds (default 4; 32 was measured faster per kernel and slower per step: NOTES A.8) */
 int p4p_set_attention_variant(int v);      /* bit 0: no resident forward / dQ, bit 1: no resident dK/dV, bit 2: no two-pass (64n+1) forward, bit 3: no fused backward (T = 32n+1 <= 257), bit 4: no fused backward at T = 513 (the streaming dQ + key-stationary dK/dV pair instead), bit 5: no start-time shift of the first round of the fused / key-stationary backward, bit 6: no key-stationary dK/dV at T = 513, bit 7: a workgroup per (b,h) pair instead of the one-workgroup-per-CU walk, bits 8-9: shift phases - 1 and bits 10..: shift in 1024-cycle units (sweeps only) */
 int p4p_set_attention_fwd_variant(int v);  /* forward only, experiments: bit 0: the K/V-resident forward at T = 513 (attention_fwd2.h, another tile order: tests/emulate.py 'online32') instead of attn_fwd_q_kernel<2>, bit 1: a workgroup per (b,h) pair instead of the walk, bit 2: no start-time shift, bit 3: the online-softmax kernels follow the running maximum exactly (no lazy rescale: the contract of rounds 1-3), bits 4 / 5: four / two 16-query tiles per wave in the streaming kernel whatever the grid */
 /* ---- persistent kernels next to a concurrent long-lived kernel (the RCCL all-reduce of a data-parallel backward; the reference has no
