@@ -82,8 +82,12 @@ class APFTrainer(Pix4PointTrainer):
                                       depth=c.get('depth', 12), num_heads=c.get('num_heads', 12))   # additive keys
         self.model.to(self.device)
         broadcast_parameters(self.model)
-        self.reducer = (GradReducer([[p for p in self.model.parameters() if p.requires_grad]])
-                        if self.distributed else None)
+        # one bucket (only the head and the point encoder train: quirk 10); the frozen parameters are remembered so that one
+        # unfrozen later is refused instead of silently staying local to its rank; CUs for RCCL as in ddp.build_reducer
+        self.reducer = (GradReducer([[p for p in self.model.parameters() if p.requires_grad]],
+                                    outside=list(self.model.parameters())) if self.distributed else None)
+        if self.reducer is not None:
+            self.reducer.reserve_cus()
 
     # ---- reference :84-146
     def _init_datasets(self) -> None:
@@ -167,29 +171,35 @@ class APFTrainer(Pix4PointTrainer):
     # ---- reference :205-247: the scheduler is stepped with the epoch index after the test phase
     def train(self) -> None:
         best_acc = 0.0
-        for epoch in range(self.train_config['epochs']):
+        if self.reducer is not None:
+            self.reducer.reserve_cus()
+        try:
+            for epoch in range(self.train_config['epochs']):
+                if self.rank == 0:
+                    print(f"\nEpoch {epoch+1}/{self.train_config['epochs']}")
+                    print(f"Current learning rate: {self.optimizer.param_groups[0]['lr']:.6f}")
+                if self.distributed:
+                    self.train_loader.sampler.set_epoch(epoch)
+                train_loss, train_acc = self._train_epoch()
+                test_loss, test_acc = self._test_epoch()
+                if self.rank == 0:
+                    self._update_metrics_csv(epoch, train_loss, train_acc, test_loss, test_acc)
+                    if test_acc > best_acc:
+                        best_acc = test_acc
+                        self._save_checkpoint("model_best.pt", epoch, test_acc)
+                        print(f"New best model saved with accuracy: {best_acc:.4f}")
+                    if (epoch + 1) % self.train_config['save_interval'] == 0:
+                        self._save_checkpoint(f"model_epoch_{epoch+1}.pt", epoch, test_acc)
+                    print(f"Epoch {epoch+1} results:")
+                    print(f"  Train Loss: {train_loss:.4f}, Train Accuracy: {train_acc:.4f}")
+                    print(f"  Test Loss: {test_loss:.4f}, Test Accuracy: {test_acc:.4f}")
+                self.scheduler.step(epoch)
             if self.rank == 0:
-                print(f"\nEpoch {epoch+1}/{self.train_config['epochs']}")
-                print(f"Current learning rate: {self.optimizer.param_groups[0]['lr']:.6f}")
-            if self.distributed:
-                self.train_loader.sampler.set_epoch(epoch)
-            train_loss, train_acc = self._train_epoch()
-            test_loss, test_acc = self._test_epoch()
-            if self.rank == 0:
-                self._update_metrics_csv(epoch, train_loss, train_acc, test_loss, test_acc)
-                if test_acc > best_acc:
-                    best_acc = test_acc
-                    self._save_checkpoint("model_best.pt", epoch, test_acc)
-                    print(f"New best model saved with accuracy: {best_acc:.4f}")
-                if (epoch + 1) % self.train_config['save_interval'] == 0:
-                    self._save_checkpoint(f"model_epoch_{epoch+1}.pt", epoch, test_acc)
-                print(f"Epoch {epoch+1} results:")
-                print(f"  Train Loss: {train_loss:.4f}, Train Accuracy: {train_acc:.4f}")
-                print(f"  Test Loss: {test_loss:.4f}, Test Accuracy: {test_acc:.4f}")
-            self.scheduler.step(epoch)
-        if self.rank == 0:
-            print(f"\nTraining completed. Best test accuracy: {best_acc:.4f}")
-            print(f"Training metrics saved to {self.metrics_csv_path}")
+                print(f"\nTraining completed. Best test accuracy: {best_acc:.4f}")
+                print(f"Training metrics saved to {self.metrics_csv_path}")
+        finally:
+            if self.reducer is not None:
+                self.reducer.release_cus()
 
     def _train_epoch(self):
         sched, self.scheduler = self.scheduler, _NoStep()          # the shared loop steps a per-epoch scheduler itself

@@ -2,7 +2,7 @@
 at a time inside DataLoader workers at ``src/data/scanobjectnn.py:186-212``).  A whole batch (B,N,3) already in HBM goes through
 ONE kernel (``csrc/augment.hip``: one workgroup per cloud, the cloud in LDS for the whole chain); the random draws are made here
 with a ``torch.Generator`` on the device and handed to the kernel as inputs, so results are reproducible and parity with the
-numpy functions is checked draw for draw (``tests/test_gpu_augment.py``).
+numpy functions is checked draw for draw (``tests/test_gpu_06_augment.py``).
 
 Function names and arguments follow ``src/data/augment.py``; the ``random_*`` functions take the draw they would make as an
 explicit argument (``None`` = draw it), clouds are (B,N,3) fp32 device tensors.

@@ -40,7 +40,7 @@ class GradReducer:
         outside: the model's parameters that are in NO bucket (frozen or never used at build time); finish() refuses a step in
         which one of them turned trainable or received a gradient (it would never be all-reduced).
         force_collectives: launch the all-reduces at world size 1 too (a process group must exist) -- the single-GPU
-        rehearsal of the RCCL stream hand-off, tests/test_gpu_ddp.py."""
+        rehearsal of the RCCL stream hand-off, tests/test_gpu_09_ddp.py."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.grad_scale = 1.0 / self.world
@@ -72,7 +72,36 @@ class GradReducer:
         inside = {id(p) for p in params}
         self._outside = [p for p in (outside or []) if id(p) not in inside]
         self._stale_zeroed = 0             # regions finish() had to zero (a block whose backward did not write): diagnostic
-        self.reserved_cus = None           # what build_reducer told the library to leave to RCCL (None: untouched)
+        self.reserved_cus = None           # what reserve_cus() told the library to leave to RCCL (None: untouched)
+        self._cus_before = None            # the library's value before reserve_cus(): release_cus() puts it back
+
+    # -- compute units for the collectives ---------------------------------------------------
+    def reserve_cus(self, reserved_cus=None):
+        """Size this library's one-round grids to CUs - r while this reducer is in use (planned_reserved_cus decides r: an
+        explicit value, P4P_RESERVED_CUS, or RCCL's channel bound when the group's backend is RCCL and world > 1; host-side
+        backends such as gloo hold no CUs and reserve nothing).  The setting is library-global and changes the summation order
+        of the weight-gradient M-splits (not the forward), so it is restored by release_cus() -- trainers call that in
+        train()'s finally; a model evaluated afterwards runs on all CUs again.  Returns the value set, None if untouched."""
+        if reserved_cus is None:
+            reserved_cus = getattr(self, '_cus_asked', None)            # a later call (train() after release_cus()) repeats the first
+        self._cus_asked = reserved_cus
+        r = planned_reserved_cus(self.world, reserved_cus, _backend_of(self.group))
+        if r is None:
+            return None
+        from . import ops
+        before = ops.set_reserved_cus(r)
+        if self._cus_before is None:
+            self._cus_before = before
+        self.reserved_cus = r
+        return r
+
+    def release_cus(self):
+        """Undo reserve_cus(): the library goes back to the value it had before this reducer changed it."""
+        if self._cus_before is not None:
+            from . import ops
+            ops.set_reserved_cus(self._cus_before)
+            self._cus_before = None
+            self.reserved_cus = None
 
     def register_block(self, params: Iterable[torch.nn.Parameter]):
         """Declare one block (a run of consecutive parameters of one bucket that the backward writes as a unit): finish()
@@ -167,10 +196,17 @@ class GradReducer:
             self.flat.mul_(self.grad_scale)
 
     def describe(self):
-        """Bucket layout for logs / bench.py: count, bytes per bucket (in readiness order, the tail last), reserved CUs."""
-        return {'buckets': len(self.buckets), 'bucket_bytes': [(e - s) * 4 for s, e in self.buckets],
-                'total_bytes': int(self.flat.numel()) * 4, 'reserved_cus': self.reserved_cus,
-                'collectives_launched': self.collectives_launched}
+        """Bucket layout for logs / bench.py: count, bytes per bucket (in readiness order, the tail last), the reserved CUs asked
+        for and what the library made of them (it rounds r up to a multiple of 8 and never goes below a grid of 64: the
+        effective figure is CUs - persistent grid)."""
+        d = {'buckets': len(self.buckets), 'bucket_bytes': [(e - s) * 4 for s, e in self.buckets],
+             'total_bytes': int(self.flat.numel()) * 4, 'reserved_cus': self.reserved_cus,
+             'collectives_launched': self.collectives_launched}
+        if self.reserved_cus is not None and self.flat.is_cuda:
+            from . import ops
+            cus, grid = ops.device_cu_count(), ops.persistent_grid_size()
+            d['reserved_cus_effective'] = (cus - grid) if (cus > 0 and grid > 0) else None      # None: persistent kernels off (r < 0)
+        return d
 
     def zero_grad(self):
         """Only the tail bucket accumulates (autograd adds into its views); the block buckets are overwritten by the
@@ -191,25 +227,34 @@ def configure_rccl_env(max_channels=RCCL_MAX_CHANNELS):
     return int(os.environ['NCCL_MAX_NCHANNELS'])
 
 
-def reserve_cus_for_collectives(world, reserved_cus=None):
-    """RCCL's all-reduce workgroups are long-lived and cannot share a CU with this library's kernels that size ONE round of
-    workgroups to the chip -- the persistent short-K GEMM tile loop, the walking attention backward (every byte of a CU's LDS)
-    and the weight-gradient GEMM's M-splits: with r CUs held, r of those workgroups start only when others have finished, with
-    their whole share still to do, and the launch takes twice as long.  One-GPU rehearsal with r parked stand-in workgroups
-    (tools/contention_rehearsal.py, N=1024 step, 51.4 ms alone): 72.2 ms with r = 8 and no remedy, 55.9 ms with all those grids
-    on CUs - r (p4p_set_reserved_cus), 62.1 ms with a workgroup per tile / pair (r < 0: the weight gradients keep 256 splits).
-    Default at world > 1: r = NCCL_MAX_NCHANNELS (configure_rccl_env: 32), i.e. what RCCL can take at most; r = 8 and r = 32
-    cost the same here (tile counts quantise alike).  ``reserved_cus`` / P4P_RESERVED_CUS override; world 1 leaves the library
-    alone.  Returns the value set, None if untouched."""
-    if reserved_cus is None and 'P4P_RESERVED_CUS' in os.environ:
-        reserved_cus = int(os.environ['P4P_RESERVED_CUS'])
-    if reserved_cus is None:
-        if world <= 1:
-            return None
-        reserved_cus = int(os.environ.get('NCCL_MAX_NCHANNELS', RCCL_MAX_CHANNELS))
-    from . import ops
-    ops.set_reserved_cus(reserved_cus)
-    return reserved_cus
+def _backend_of(group=None):
+    if not dist.is_initialized():
+        return None
+    try:
+        return str(dist.get_backend(group))
+    except Exception:                                       # pragma: no cover - a group this rank is not part of
+        return None
+
+
+def planned_reserved_cus(world, reserved_cus=None, backend=None):
+    """How many CUs a reducer for this world / backend asks the library to leave free, WITHOUT setting anything (tests take
+    their reference pass under the same value).  RCCL's all-reduce workgroups are long-lived and cannot share a CU with this
+    library's kernels that size ONE round of workgroups to the chip -- the persistent short-K GEMM tile loop, the walking
+    attention backward (every byte of a CU's LDS) and the weight-gradient GEMM's M-splits: with r CUs held, r of those
+    workgroups start only when others have finished, with their whole share still to do, and the launch takes twice as long.
+    One-GPU rehearsal with r parked stand-in workgroups (tools/contention_rehearsal.py, N=1024 step, 51.4 ms alone): 72.2 ms
+    with r = 8 and no remedy, 55.9 ms with all those grids on CUs - r (p4p_set_reserved_cus), 62.1 ms with a workgroup per
+    tile / pair (r < 0: the weight gradients keep 256 splits).
+    Order: the explicit argument; P4P_RESERVED_CUS; world > 1 on RCCL ('nccl'): NCCL_MAX_NCHANNELS (configure_rccl_env: 32),
+    i.e. what RCCL can take at most (r = 8 and r = 32 cost the same: tile counts quantise alike); otherwise None -- world 1,
+    and host-side backends (gloo collectives run on the CPU and hold no CU), leave the library alone."""
+    if reserved_cus is not None:
+        return int(reserved_cus)
+    if 'P4P_RESERVED_CUS' in os.environ:
+        return int(os.environ['P4P_RESERVED_CUS'])
+    if world > 1 and backend is not None and 'nccl' in backend:
+        return int(os.environ.get('NCCL_MAX_NCHANNELS', RCCL_MAX_CHANNELS))
+    return None
 
 
 def build_reducer(model, process_group=None, bucket_mb=None, force_collectives=False, reserved_cus=None) -> GradReducer:
@@ -240,7 +285,7 @@ def build_reducer(model, process_group=None, bucket_mb=None, force_collectives=F
     counts.append(0)
     red = GradReducer(buckets, process_group, blocks_per_bucket=counts, outside=list(model.parameters()),
                       force_collectives=force_collectives)
-    red.reserved_cus = reserve_cus_for_collectives(red.world, reserved_cus)
+    red.reserve_cus(reserved_cus)
     for blk in blocks:
         bp = [p for p in block_params(blk) if p.requires_grad]
         if bp and len(bp) == 12:

@@ -13,7 +13,7 @@ from . import ops
 
 # tests set this to a dict to receive the tensors every stage of the next forward passes on (tokenizer activations, the two
 # token streams, per block: xin / ln1 / qkv / att / x1 / ln2 / g / xout, and the final LayerNorm output), so that a PyTorch
-# statement can be checked LINK BY LINK against the pipeline's own upstream tensors (tests/test_gpu_matched_parity.py)
+# statement can be checked LINK BY LINK against the pipeline's own upstream tensors (tests/test_gpu_03_matched_parity.py)
 _CAPTURE = None
 _CAPTURE_BWD = None        # tests only: a dict that the encoder's backward fills with every block's upstream gradient
 _FREE_DSTACK_EARLY = False    # encoder backward: copy the returned block-input gradient out of the slab stack so that the stack is freed before the

@@ -592,6 +592,11 @@ def set_reserved_cus(r):
     return L.call_int('p4p_set_reserved_cus', int(r))
 
 
+def device_cu_count():
+    """Compute units of the current device (-1 if the runtime cannot say)."""
+    return L.call_int('p4p_device_cu_count')
+
+
 def persistent_grid_size():
     """Workgroups a persistent launch takes on the current device now (0: no persistent kernels are launched)."""
     return L.call_int('p4p_persistent_grid_size')

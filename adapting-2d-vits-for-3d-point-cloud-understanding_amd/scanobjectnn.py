@@ -7,11 +7,11 @@ Differences, stated:
   in this image, so the same path is tried with ``.h5`` when h5py can be imported and with ``.npz`` (arrays ``data`` (M,P,3)
   float32 and ``label`` (M,)) otherwise -- ``numpy.savez(path, data=f['data'][:], label=f['label'][:])`` converts a file;
 * dataset-level FPS (``sampling_method='fps'``, :92-97: ``fps(points.cuda(), num_points)`` over the WHOLE array in one
-  Python-loop call) runs through the HIP kernel (``p4p_fps_f32``, bit-identical algorithm: tests/test_gpu_apf.py) in chunks of
+  Python-loop call) runs through the HIP kernel (``p4p_fps_f32``, bit-identical algorithm: tests/test_gpu_05_apf.py) in chunks of
   clouds; the reference draws the start indices unseeded (sampler.py:20), here they come from ``fps_seed`` (None = unseeded; in a multi-rank run one seed drawn by rank 0 is shared, so all ranks subsample alike);
 * the per-sample numpy augmentations of ``__getitem__`` (:186-212) and the dict transforms of the APF trainer are applied to
   the DEVICE BATCH by the trainers (p4p_amd.augment: one kernel launch per batch, draw-for-draw parity with the reference's
-  functions in tests/test_gpu_augment.py), so ``__getitem__`` returns the sampled (and, if asked, normalised) cloud;
+  functions in tests/test_gpu_06_augment.py), so ``__getitem__`` returns the sampled (and, if asked, normalised) cloud;
   ``use_custom_augmentation`` / ``augmentation_probability`` / ``transform`` / ``use_height`` are kept as attributes for them.
 """
 import os

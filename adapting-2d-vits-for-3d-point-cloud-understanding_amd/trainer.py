@@ -166,26 +166,32 @@ class Pix4PointTrainer:
     # ---- reference :135-151
     def train(self) -> None:
         best_acc = 0.0
-        for epoch in range(getattr(self, 'start_epoch', 0), self.train_config['epochs']):      # > 0 after load_checkpoint
+        if self.reducer is not None:
+            self.reducer.reserve_cus()                  # CUs for RCCL while training (no-op if build_reducer's still holds)
+        try:
+            for epoch in range(getattr(self, 'start_epoch', 0), self.train_config['epochs']):      # > 0 after load_checkpoint
+                if self.rank == 0:
+                    print(f"\nEpoch {epoch+1}/{self.train_config['epochs']}")
+                if self.distributed:
+                    self.train_loader.sampler.set_epoch(epoch)
+                train_loss, train_acc = self._train_epoch()
+                test_loss, test_acc = self._test_epoch()
+                if self.rank == 0:
+                    self._update_metrics_csv(epoch, train_loss, train_acc, test_loss, test_acc)
+                    if test_acc > best_acc:
+                        best_acc = test_acc
+                        self._save_checkpoint("best_model.pt", epoch, best_acc)
+                    if (epoch + 1) % self.train_config['save_interval'] == 0:
+                        self._save_checkpoint(f"model_epoch_{epoch+1}.pt", epoch, test_acc)
+                    print(f"Epoch {epoch+1} results:")
+                    print(f"  Train Loss: {train_loss:.4f}, Train Accuracy: {train_acc:.4f}")
+                    print(f"  Test Loss: {test_loss:.4f}, Test Accuracy: {test_acc:.4f}")
             if self.rank == 0:
-                print(f"\nEpoch {epoch+1}/{self.train_config['epochs']}")
-            if self.distributed:
-                self.train_loader.sampler.set_epoch(epoch)
-            train_loss, train_acc = self._train_epoch()
-            test_loss, test_acc = self._test_epoch()
-            if self.rank == 0:
-                self._update_metrics_csv(epoch, train_loss, train_acc, test_loss, test_acc)
-                if test_acc > best_acc:
-                    best_acc = test_acc
-                    self._save_checkpoint("best_model.pt", epoch, best_acc)
-                if (epoch + 1) % self.train_config['save_interval'] == 0:
-                    self._save_checkpoint(f"model_epoch_{epoch+1}.pt", epoch, test_acc)
-                print(f"Epoch {epoch+1} results:")
-                print(f"  Train Loss: {train_loss:.4f}, Train Accuracy: {train_acc:.4f}")
-                print(f"  Test Loss: {test_loss:.4f}, Test Accuracy: {test_acc:.4f}")
-        if self.rank == 0:
-            print(f"\nTraining completed. Best test accuracy: {best_acc:.4f}")
-            print(f"Training metrics saved to {self.metrics_csv_path}")
+                print(f"\nTraining completed. Best test accuracy: {best_acc:.4f}")
+                print(f"Training metrics saved to {self.metrics_csv_path}")
+        finally:
+            if self.reducer is not None:
+                self.reducer.release_cus()              # whatever runs after training in this process gets all CUs back
 
     def _reduce_epoch(self, loss_sum, correct, total, batches) -> Tuple[float, float]:
         stats = torch.stack([loss_sum, correct.float(), torch.tensor(float(total), device=loss_sum.device),

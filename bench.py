@@ -134,7 +134,10 @@ class ApfStepper:
                                                   in_channels=4).to(device)     # reference train_apf.py:5: xyz + height
         self.model.train()
         broadcast_parameters(self.model)
-        self.reducer = GradReducer([[p for p in self.model.parameters() if p.requires_grad]]) if distributed else None
+        self.reducer = (GradReducer([[p for p in self.model.parameters() if p.requires_grad]], outside=list(self.model.parameters()))
+                        if distributed else None)
+        if self.reducer is not None:
+            self.reducer.reserve_cus()
         self.opt = FusedAdamW(self.model.parameters(), lr=5e-4, weight_decay=5e-2)
         self.crit = torch.nn.CrossEntropyLoss(label_smoothing=0.3)
 
@@ -524,7 +527,7 @@ def main():
     if distributed:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        # rehearsal switches for a one-GPU box (tests/test_gpu_ddp.py style): P4P_DIST_BACKEND=gloo P4P_SINGLE_DEVICE=1 runs
+        # rehearsal switches for a one-GPU box (tests/test_gpu_09_ddp.py style): P4P_DIST_BACKEND=gloo P4P_SINGLE_DEVICE=1 runs
         # all ranks on device 0 with host-side collectives, to exercise the multi-rank control flow of this file
         backend = os.environ.get('P4P_DIST_BACKEND', 'nccl')
         if os.environ.get('P4P_SINGLE_DEVICE'):

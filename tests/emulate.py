@@ -381,7 +381,7 @@ def block_emulated(xin, blk, B, T, H, tape, l=0, matched_attention_backward=None
 def pix4point_emulated(oracle, pts, idx_fps, idx_knn, training=False, tape=None):
     """Logits of oracle (an oracle.pix4point_oracle.Pix4Point ON THE SAME DEVICE as pts) evaluated the way the HIP
     pipeline evaluates them.  idx_fps (B,S) int64 / idx_knn (B,S,k) int32 come from the oracle's index functions (the
-    kernels are bit-exact on those: tests/test_gpu_kernels.py).  training=True: batch statistics in the tokenizer's and
+    kernels are bit-exact on those: tests/test_gpu_01_kernels.py).  training=True: batch statistics in the tokenizer's and
     the head's BatchNorm (set oracle.train() and the dropout probabilities to 0 first).  tape: see Tape."""
     tape = tape or Tape()
     pv = oracle.model

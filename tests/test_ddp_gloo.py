@@ -168,3 +168,42 @@ def test_force_collectives_needs_a_process_group():
     lin = torch.nn.Linear(4, 4)
     with pytest.raises(RuntimeError, match='process group'):
         GradReducer([list(lin.parameters())], force_collectives=True)
+
+
+def test_reserved_cu_plan_follows_backend_and_environment(monkeypatch):
+    """the CUs left to the collectives are decided in ONE place, and only a backend that runs on the GPU gets any
+    (gloo's collectives run on the host: reserving 32 CUs for them only slowed the rehearsals down)."""
+    from p4p_amd.ddp import planned_reserved_cus
+    monkeypatch.delenv('P4P_RESERVED_CUS', raising=False)
+    monkeypatch.delenv('NCCL_MAX_NCHANNELS', raising=False)
+    assert planned_reserved_cus(1, None, 'nccl') is None            # world 1: the library is left alone
+    assert planned_reserved_cus(8, None, 'gloo') is None            # host-side collectives hold no CU
+    assert planned_reserved_cus(8, None, None) is None
+    assert planned_reserved_cus(8, None, 'nccl') == 32              # RCCL's channel bound (configure_rccl_env default)
+    assert planned_reserved_cus(8, None, 'cuda:nccl,cpu:gloo') == 32
+    monkeypatch.setenv('NCCL_MAX_NCHANNELS', '16')
+    assert planned_reserved_cus(8, None, 'nccl') == 16
+    monkeypatch.setenv('P4P_RESERVED_CUS', '8')
+    assert planned_reserved_cus(8, None, 'nccl') == 8 and planned_reserved_cus(1, None, 'gloo') == 8
+    assert planned_reserved_cus(8, 0, 'nccl') == 0                  # the explicit argument wins
+
+
+def test_reserved_cus_are_a_handle_that_release_restores():
+    """building a reducer must not leave the process on CUs - 32 for good."""
+    from p4p_amd import ops
+    lin = torch.nn.Linear(4, 4)
+    start = ops.set_reserved_cus(8)
+    try:
+        red = GradReducer([list(lin.parameters())])
+        assert red.reserve_cus() is None and red.reserved_cus is None       # world 1, no request: untouched
+        assert ops.set_reserved_cus(8) == 8
+        assert red.reserve_cus(24) == 24 and red.reserved_cus == 24
+        assert red.reserve_cus() == 24                                      # a later call repeats the first request ...
+        red.release_cus()
+        assert red.reserved_cus is None and ops.set_reserved_cus(8) == 8    # ... and release puts back what was there BEFORE it
+        red.release_cus()                                                   # idempotent
+        assert ops.set_reserved_cus(8) == 8
+        assert red.reserve_cus() == 24                                      # train() after release_cus(): reserved again
+        red.release_cus()
+    finally:
+        ops.set_reserved_cus(start)

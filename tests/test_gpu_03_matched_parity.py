@@ -1,6 +1,6 @@
 """The north star's float tolerance (logits within 1e-3), asserted the only way two bf16 pipelines can be compared.
 
-bf16 MFMA operands put the build 4e-3..7e-3 from the PURE fp32 oracle on O(1) logits (tests/test_gpu_model.py keeps
+bf16 MFMA operands put the build 4e-3..7e-3 from the PURE fp32 oracle on O(1) logits (tests/test_gpu_02_model.py keeps
 that comparison at 1e-2 and shows stock torch bf16 has the same error).  That window is too wide to catch a kernel-logic
 error of a few 1e-3, so the whole model is compared with the oracle's arithmetic ROUNDED WHERE THE PIPELINE ROUNDS
 (tests/emulate.py, tied to the oracle on the CPU by tests/test_emulation_cpu.py: with the roundings off it IS the oracle):
@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 import p4p_amd                                    # noqa: E402
 from oracle import pix4point_oracle as O          # noqa: E402
 from tests import emulate as E                    # noqa: E402
-from tests.test_gpu_model import build_pair, rel_l2, _no_dropout      # noqa: E402
+from tests.test_gpu_02_model import build_pair, rel_l2, _no_dropout      # noqa: E402
 
 DEV = 'cuda'
 NORTH_STAR_TOL = E.NORTH_STAR_TOL

@@ -2,7 +2,7 @@
 the reference-generated fixtures (tests/golden/apf_*.npz) and the CPU oracle (oracle/apf_oracle.py).
 
 Index outputs (FPS picks, Morton codes and order, group membership) are bit-exact.  Floating point is bf16 MFMA operands
-with fp32 accumulation against an fp32 oracle; bounds follow tests/test_gpu_model.py: activations / logits 1e-2 relative
+with fp32 accumulation against an fp32 oracle; bounds follow tests/test_gpu_02_model.py: activations / logits 1e-2 relative
 L2, gradients of smooth pieces 3e-2, gradients through hard gates (ReLU, max-pool) 5e-2 with a well-conditioned upstream
 gradient.
 """

@@ -188,7 +188,7 @@ def test_training_trajectory_tracks_the_cpu_oracle(which):
     """Six FusedAdamW steps of the HIP model on one batch; at every step the fp32 CPU oracle, given the HIP model's current
     weights, must compute the same loss.  This is the end-to-end check that the UPDATED weights are the ones the next forward
     uses (GEMM operand copies re-made after every fused step) and that training moves; the update rule itself is compared
-    with torch.optim.AdamW in tests/test_gpu_optim.py."""
+    with torch.optim.AdamW in tests/test_gpu_04_optim.py."""
     from oracle import pix4point_oracle as O
     from oracle import apf_oracle as A
     from p4p_amd.optim import FusedAdamW

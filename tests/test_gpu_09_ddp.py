@@ -22,12 +22,29 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, bucket_mb=None):
+def _grad_table(named, want_of, block_names):
+    """[(name, max|want|, max|delta|, bit_equal, in_block)] for every parameter with a gradient; a NaN / Inf anywhere fails by NAME
+    (a plain max() over floats would drop a NaN silently)."""
+    rows = []
+    for n, p in named:
+        want = want_of(n)
+        if want is None:
+            assert p.grad is None, f'{n}: a gradient appeared that the plain-autograd pass did not produce'
+            continue
+        assert p.grad is not None, f'{n}: no gradient'
+        assert bool(torch.isfinite(p.grad).all()), f'{n}: non-finite gradient (a poisoned bucket element survived the step)'
+        rows.append((n, float(want.abs().max()), float((p.grad - want).abs().max()), bool(torch.equal(p.grad, want)), n in block_names))
+    return rows
+
+
+def _worker(rank, world, port, q, bucket_mb=None, reserved=None):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         import p4p_amd
-        from p4p_amd.ddp import broadcast_parameters, build_reducer
+        from p4p_amd import ops
+        from p4p_amd.ddp import broadcast_parameters, build_reducer, planned_reserved_cus
+        from p4p_amd.functional import block_params
         from oracle import pix4point_oracle as O
         dev = 'cuda:0'
         torch.manual_seed(10 + rank)                       # different init per rank: broadcast must fix it
@@ -41,34 +58,71 @@ def _worker(rank, world, port, q, bucket_mb=None):
         pts = O.synthetic_clouds(8, 256, seed=50 + rank).to(dev)
         start = (torch.arange(8) * 3).to(dev)
         labels = torch.randint(0, 40, (8,), generator=torch.Generator().manual_seed(rank)).to(dev)
-
-        # local gradients through plain autograd (no reducer), BN buffers restored afterwards
         bufs = [b.detach().clone() for b in model.buffers()]
+
+        def restore_buffers():
+            for b, v in zip(model.buffers(), bufs):
+                b.copy_(v)
+
+        # The reserved CUs decide the M-split count (= summation order) of the weight-gradient GEMMs: the reference pass must run
+        # under the value the reducer is going to set, or "plain autograd" and "reducer" are two different computations.
+        # gloo collectives hold no CU, so the default plan is None here; `reserved` exercises the CUs - r grids of a real RCCL run.
+        plan = planned_reserved_cus(world, reserved, 'gloo')
+        assert plan == reserved
+        before = ops.set_reserved_cus(plan if plan is not None else 0)
+        # one unchecked warm-up step: stock-torch ops of the head (hipBLASLt Linear, MIOpen BatchNorm1d) settle on an algorithm
         torch.nn.functional.cross_entropy(model(pts, start), labels).backward()
+        model.zero_grad(set_to_none=True)
+        restore_buffers()
+        # local gradients through plain autograd (no reducer), BN buffers restored afterwards; the gradient the stock-torch head
+        # hands the encoder is kept, so that the second pass can say whether it received the same bits
+        from p4p_amd import functional as F
+        F._CAPTURE_BWD = cap1 = {}
+        torch.nn.functional.cross_entropy(model(pts, start), labels).backward()
+        F._CAPTURE_BWD = None
         local = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
         model.zero_grad(set_to_none=True)
-        for b, v in zip(model.buffers(), bufs):
-            b.copy_(v)
+        restore_buffers()
 
-        red = build_reducer(model, bucket_mb=bucket_mb)
-        assert len(red.buckets) == (2 if bucket_mb else 3)      # 2 blocks (+ tail); merged into one bucket when asked
+        red = build_reducer(model, bucket_mb=bucket_mb, reserved_cus=reserved)
+        assert red.reserved_cus == plan and len(red.buckets) == (2 if bucket_mb else 3)      # 2 blocks (+ tail); merged when asked
         opt = torch.optim.AdamW(model.get_param_groups(), lr=1e-3, weight_decay=5e-2, fused=True)
         red.zero_grad()
         red.flat.fill_(float('nan'))                            # the block buckets are OVERWRITTEN by the backward kernels ...
         red.zero_grad()                                         # ... only the tail bucket accumulates and is zeroed
+        F._CAPTURE_BWD = cap2 = {}
         torch.nn.functional.cross_entropy(model(pts, start), labels).backward()
+        F._CAPTURE_BWD = None
         red.finish()
-        worst = 0.0
-        for n, p in model.named_parameters():
-            if n not in local:
-                assert p.grad is None, n
-                continue
+        same_upstream = torch.equal(cap1['block_dout'][1], cap2['block_dout'][1])      # top block's incoming gradient, both passes
+
+        want = {}
+        for n in local:                                         # the mean of the per-rank local gradients, summed in rank order as gloo does
             both = [torch.zeros_like(local[n]) for _ in range(world)]
             dist.all_gather(both, local[n])
-            want = sum(both) / world
-            err = float((p.grad - want).abs().max()) / max(float(want.abs().max()), 1e-6)
-            worst = max(worst, err)
-        assert worst < 1e-5, worst                          # same kernels, same inputs: only summation order differs
+            want[n] = sum(both) / world
+        ids = {id(p) for blk in model.model.vit_blocks for p in block_params(blk)}
+        block_names = {n for n, p in model.named_parameters() if id(p) in ids}
+        rows = _grad_table(model.named_parameters(), want.get, block_names)
+        gmax = max(r[1] for r in rows)                          # the step's gradient scale
+        # (1) the block buckets are WRITTEN by the HIP kernels (weight-gradient GEMMs straight into the views, the eight vectors
+        #     copied) under the same reserved CUs as the reference pass: the same kernels on the same inputs give the same bits.
+        #     "Same inputs" is checked, not assumed: the encoder's incoming gradient comes from the stock-torch head (hipBLASLt /
+        #     MIOpen), which this library does not control; every box measured so far returned it bit-identical (tools/
+        #     ddp_race_diag.py: 10 passes x 4 concurrent processes), and then bit-equality is asserted; if a box ever does not,
+        #     the blocks fall under the tolerance of (2) and the message says so.
+        bad = [(n, w, d) for n, w, d, eq, blk in rows if blk and not eq]
+        if same_upstream:
+            assert not bad, f'block gradients differ from the mean of the local gradients: {sorted(bad, key=lambda r: -r[2])[:5]}'
+        # (2) the tail bucket is accumulated by autograd from stock-torch and HIP producers.  Several of its tensors are ZERO in exact
+        #     arithmetic (a bias in front of a train-mode BatchNorm: cls_head.head.{0,4}.bias, patch_embed.convs.0.0.1.bias; the shift
+        #     of the final LayerNorm that BatchNorm removes): their values are the rounding noise of sums of terms at the gradient
+        #     scale (max|g| = 5.6e-9 ... 2e-5 against gmax ~ 1e-1).  An error relative to such a tensor's own maximum is noise / noise;
+        #     every tensor is therefore measured against max(its own maximum, 1e-3 * the step's largest gradient).
+        worst = max(((d / max(w, 1e-3 * gmax), n, w, d) for n, w, d, eq, blk in rows if not (blk and same_upstream)),
+                    default=(0.0, '', 0.0, 0.0))
+        assert worst[0] < 1e-5, (f'gradient {worst[1]}: max|delta| = {worst[3]:.3e}, max|want| = {worst[2]:.3e}, gmax = {gmax:.3e}, '
+                                 f'head gradient bit-identical in both passes: {same_upstream}')
         # the fused tail on SUMS with 1/world folded into the clip coefficient == stock clip + AdamW on the averages
         from p4p_amd.optim import FusedAdamW
         import copy
@@ -85,7 +139,10 @@ def _worker(rank, world, port, q, bucket_mb=None):
             g = [torch.zeros_like(p.data) for _ in range(world)]
             dist.all_gather(g, p.data)
             assert torch.equal(g[0], g[1]), f'{n} diverged across ranks'
-        q.put((rank, 'ok', worst))
+        # the reservation is a handle: releasing it puts the library back where it was before build_reducer
+        red.release_cus()
+        assert ops.set_reserved_cus(before) == (plan if plan is not None else 0)
+        q.put((rank, 'ok', worst[0], same_upstream))
     except Exception:                                       # pragma: no cover
         import traceback
         q.put((rank, traceback.format_exc(), 0.0))
@@ -145,7 +202,7 @@ def _nccl_world1_worker(port, q):
         fb.step(max_norm=0.05)
         for (n, p), (_, t) in zip(model.named_parameters(), twin.named_parameters()):
             assert torch.equal(p, t), n
-        # (d) a second step reuses the views; with the persistent kernels switched off as build_reducer does at world > 1
+        # (d) a second step reuses the views; with the persistent kernels switched off (r < 0: a workgroup per tile / pair)
         ops.set_reserved_cus(-1)
         for mdl, rd in ((model, red), (twin, None)):
             if rd is not None:
@@ -179,12 +236,12 @@ def test_rccl_world_size_one_reducer_runs_real_collectives():
     assert res == 'ok', res
 
 
-@pytest.mark.parametrize('bucket_mb', [None, 100.0])
-def test_two_rank_data_parallel_step_on_one_gpu(bucket_mb):
+@pytest.mark.parametrize('bucket_mb,reserved', [(None, None), (100.0, 32)])
+def test_two_rank_data_parallel_step_on_one_gpu(bucket_mb, reserved):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, bucket_mb)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, bucket_mb, reserved)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]

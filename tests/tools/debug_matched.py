@@ -11,7 +11,7 @@ import p4p_amd                                    # noqa: E402
 from p4p_amd import functional as F, ops          # noqa: E402
 from oracle import pix4point_oracle as O          # noqa: E402
 from tests import emulate as E                    # noqa: E402
-from tests.test_gpu_model import build_pair       # noqa: E402
+from tests.test_gpu_02_model import build_pair       # noqa: E402
 
 DEV = 'cuda'
 

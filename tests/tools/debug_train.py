@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch, numpy as np
 import p4p_amd
 from oracle import pix4point_oracle as O
-from tests.test_gpu_model import build_pair, rel_l2
+from tests.test_gpu_02_model import build_pair, rel_l2
 
 D, L, H, B, N = 192, 2, 3, 32, 256
 oracle, model = build_pair(40, D, L, H, seed=11)

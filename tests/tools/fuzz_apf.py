@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', '..'))
 import p4p_amd
 from p4p_amd import apf as PA
 from oracle import apf_oracle as A
-from tests.test_gpu_apf import rel_l2, _layer_pair, _model_pair
+from tests.test_gpu_05_apf import rel_l2, _layer_pair, _model_pair
 
 DEV = 'cuda'
 

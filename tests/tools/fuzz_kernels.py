@@ -1,5 +1,5 @@
 """Random-shape sweep of the kernels against their references (diagnostic, time-boxed): GEMMs on integer data (exact), weight
-gradients (exact), attention / LayerNorm / FPS / kNN through the bodies of tests/test_gpu_kernels.py at shapes the
+gradients (exact), attention / LayerNorm / FPS / kNN through the bodies of tests/test_gpu_01_kernels.py at shapes the
 parametrised tests do not list.  FUZZ_SECONDS (default 120), FUZZ_SEED."""
 import os, sys, time, traceback
 import numpy as np
@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', '..'))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import p4p_amd
 from p4p_amd import ops
-import test_gpu_kernels as T
+import test_gpu_01_kernels as T
 
 DEV = 'cuda'
 rng = np.random.default_rng(0)

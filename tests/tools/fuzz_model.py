@@ -8,8 +8,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', '..'))
 import p4p_amd
 from oracle import pix4point_oracle as O
 from tests import emulate as E
-from tests.test_gpu_model import build_pair, _no_dropout
-from tests.test_gpu_matched_parity import _captured_forward
+from tests.test_gpu_02_model import build_pair, _no_dropout
+from tests.test_gpu_03_matched_parity import _captured_forward
 
 DEV = 'cuda'
 

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', '..'))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 import p4p_amd
 from p4p_amd import ops, _lib
-import test_gpu_kernels as T
+import test_gpu_01_kernels as T
 
 lib = _lib.lib()
 rng = np.random.default_rng(int(os.environ.get('FUZZ_SEED', 0)))
