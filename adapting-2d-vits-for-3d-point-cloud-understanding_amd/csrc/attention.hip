@@ -1264,7 +1264,8 @@ extern "C" int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B,
         // measured at B=256, H=12 (tools/attn_ab.py): T=513: 542 / 499 / 533 us for 1 / 2 / 4 tiles per wave; T=2049: 5398 / 4643 / 4501
         // round 4, with the lazy rescale (tools/attn_fwd_thr_ab.py): T=513: 337 / 406 us for 2 / 4 tiles; T=2049, B=8, H=16 (128 pairs): 175.5 / 184.3 us --
         // four tiles per wave pay only when their 256-row workgroups still fill the chip many times over (B=256: 4.50 against 4.64 ms)
-        const bool many = (long long)B * H * ceil_div(T, 256) >= 16ll * p4p_device_cu_count();
+        const int ncus = p4p_device_cu_count();                    // -1 if the runtime cannot say: treated as 'not many'
+        const bool many = ncus > 0 && (long long)B * H * ceil_div(T, 256) >= 16ll * ncus;
         const int qt = (g_attn_fwd_variant & 48) ? ((g_attn_fwd_variant & 16) ? 4 : 2) : (T >= 1024 && many ? 4 : 2);     // bits 4 / 5: force 4 / 2 (A/B)
         if (qt == 2 && T > 128)
             hipLaunchKernelGGL(attn_fwd_q_kernel<2>, dim3((unsigned)(ceil_div((long long)B * H, 8) * 8 * ceil_div(T, 128))),
@@ -1289,6 +1290,22 @@ static bool attn_fused(int T) {           // attention_fused.h; needs the reside
 }
 static bool attn_resident_dkdv(int T) {
     return !(g_attn_variant & 2) && attn_resident(T);       // 4 waves x 220 VGPRs: -0.4 ms/step
+}
+static bool attn_fused2(int T) {          // attention_fused2.h: T = 513, walking workgroups (needs persistent kernels)
+    return T == 513 && !(g_attn_variant & (64 | 16)) && p4p_persistent_grid() > 0;
+}
+// floats the `delta` workspace of p4p_attention_bwd must hold for this shape under the CURRENT switches (reserved CUs, variants):
+// B*H*T for the kernels that keep delta in memory; the fused T = 513 kernel parks dQ^T chains there instead (per workgroup
+// F2Lds<16>::ROWS x 64 floats), whichever is larger
+extern "C" long long p4p_attention_bwd_workspace(int B, int T, int H) {
+    long long n = (long long)B * H * T;
+    if (attn_fused2(T)) {
+        const int pgrid = p4p_persistent_grid();
+        const long long nwg = (long long)B * H < pgrid ? (long long)B * H : pgrid;
+        const long long park = nwg * (F2Lds<16>::ROWS * 64);
+        if (park > n) n = park;
+    }
+    return n;
 }
 // the partial-row layouts of the streaming and the resident kernels differ: dq and dk/dv take the same path when sums are asked for
 extern "C" int p4p_attention_colsum_rows(int B, int T) { return attn_resident_dkdv(T) ? B * RES_COLSUM_ROWS : B * ceil_div(T, 64) * 4; }
@@ -1344,29 +1361,19 @@ extern "C" int p4p_attention_bwd(const void* qkv, const void* o, const void* dou
         P4P_LAUNCH_CHECK();
     }
     dim3 grid = attn_grid(B, T, H);
-    if (T == 513 && !(g_attn_variant & (64 | 16)) && p4p_persistent_grid() > 0) {
+    if (attn_fused2(T)) {
         // attention_fused2.h (round 4): dQ, dK, dV in ONE kernel -- a workgroup walks its pairs and takes the two key halves of a pair
-        // one after the other with Q / dO resident; half 0's dQ^T chains wait in a per-workgroup scratch (library-owned, 139 KB per
-        // workgroup).  Bit 4 of the variant: the two kernels below.
-        static float* scratch[64] = {nullptr};
-        static size_t scratch_floats[64] = {0};
-        int dev = 0;
-        P4P_HIP(hipGetDevice(&dev));
-        P4P_CHECK(dev >= 0 && dev < 64, "p4p_attention_bwd: device index %d", dev);
+        // one after the other with Q / dO resident; half 0's dQ^T chains wait in a per-workgroup slice (139 KB) of the CALLER's
+        // workspace (`delta`, sized by p4p_attention_bwd_workspace: the kernel computes delta itself and keeps it on chip).  Round 5:
+        // the parking space used to be a library-owned, function-static hipMalloc shared by every stream.  Bit 4 of the variant: the
+        // two kernels below.
         const int pgrid = p4p_persistent_grid();
         const int nwg = B * H < pgrid ? B * H : pgrid;
-        const size_t need = (size_t)nwg * (F2Lds<16>::ROWS * 64);
-        if (need > scratch_floats[dev]) {
-            if (scratch[dev]) P4P_HIP(hipFree(scratch[dev]));
-            scratch[dev] = nullptr;
-            scratch_floats[dev] = 0;
-            P4P_HIP(hipMalloc(&scratch[dev], need * sizeof(float)));
-            scratch_floats[dev] = need;
-        }
+        float* const parking = delta;
         p.stagger_n = nwg; p.stagger_phases = 3; p.stagger_cycles = 12 * 1024;
         if (g_attn_variant & 32) p.stagger_phases = 1;
         if (g_attn_variant >> 8) { p.stagger_phases = ((g_attn_variant >> 8) & 3) + 1; p.stagger_cycles = (g_attn_variant >> 10) * 1024; }
-        hipLaunchKernelGGL((attn_bwd_fused2_kernel<16, true>), dim3(nwg), dim3(512), 0, st, p, scratch[dev]);
+        hipLaunchKernelGGL((attn_bwd_fused2_kernel<16, true>), dim3(nwg), dim3(512), 0, st, p, parking);
         P4P_LAUNCH_CHECK();
         return 0;
     }

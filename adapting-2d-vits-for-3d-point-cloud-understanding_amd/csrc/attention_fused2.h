@@ -34,13 +34,14 @@
 #pragma once
 
 // Diagnostic build only (tools/attn_f2_stamps.py compiles attention.hip with -DP4P_F2_STAMPS into its own library): s_memtime stamps of
-// thread 0 at the phase boundaries of every pair, into the (otherwise unused) delta workspace.  No stamp in the product library.
+// thread 0 at the phase boundaries of every pair, into the delta workspace BEHIND the dQ^T parking space (the tool allocates
+// p4p_attention_bwd_workspace floats + 32 per pair).  No stamp in the product library.
 #ifdef P4P_F2_STAMPS
 #define F2_STAMP(k)                                                                                       \
     do {                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                \
         const unsigned long long ts_ = __builtin_readcyclecounter();                                      \
-        if (t == 0) reinterpret_cast<unsigned long long*>(p.delta)[(size_t)bh * 16 + (k)] = ts_;          \
+        if (t == 0) reinterpret_cast<unsigned long long*>(p.delta + (size_t)gridDim.x * (F2Lds<16>::ROWS * 64))[(size_t)bh * 16 + (k)] = ts_; \
         __builtin_amdgcn_sched_barrier(0);                                                                \
     } while (0)
 #else

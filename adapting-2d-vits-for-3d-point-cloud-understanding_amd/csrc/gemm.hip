@@ -65,8 +65,25 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
         *reinterpret_cast<bf16x4*>((__bf16*)out + e) = w;
     }
 }
-static float* g_splitk_ws = nullptr;       // library-owned scratch for the split-K planes (a few MB; one process per GPU)
-static size_t g_splitk_ws_floats = 0;
+// library-owned scratch for the split-K planes of the peeled tail launch (a few MB), one buffer PER DEVICE, grown on demand.
+// Threading rule of this library (include/p4p_hip.h): one host thread at a time and one stream per device -- two launches of the
+// same device on different streams would share this buffer (and the host-side switches above) without synchronisation.
+static float* g_splitk_ws[64] = {nullptr};
+static size_t g_splitk_ws_floats[64] = {0};
+static int splitk_workspace(size_t need, float** out) {
+    int dev = 0;
+    P4P_HIP(hipGetDevice(&dev));
+    P4P_CHECK(dev >= 0 && dev < 64, "p4p_gemm_tn_bf16: device index %d", dev);
+    if (need > g_splitk_ws_floats[dev]) {
+        if (g_splitk_ws[dev]) P4P_HIP(hipFree(g_splitk_ws[dev]));
+        g_splitk_ws[dev] = nullptr;
+        g_splitk_ws_floats[dev] = 0;
+        P4P_HIP(hipMalloc(&g_splitk_ws[dev], need * sizeof(float)));
+        g_splitk_ws_floats[dev] = need;
+    }
+    *out = g_splitk_ws[dev];
+    return 0;
+}
 
 template <int BM_, int BN_, int WAVES_M, int WAVES_N, int EPI, bool PIN = false, int ABL = 0>
 static int launch_cfg(const GemmParams& p, hipStream_t st) {
@@ -82,20 +99,22 @@ extern "C" int p4p_colsum_partial_bf16(const void* G, float* partial, int M, int
 extern "C" int p4p_gemm_tn_colsum_rows(int M) { return 2 * ceil_div(M, 256); }
 
 template <int EPI>
-static int launch_tn_inner(const GemmParams& p, hipStream_t st);
+static int launch_tn_inner(const GemmParams& p, hipStream_t st, int variant);
 
 template <int EPI>
 static int launch_tn(const GemmParams& p, hipStream_t st) {
     if constexpr (EPI == EPI_BF16_DGELU) {
         if (p.stats) P4P_HIP(hipMemsetAsync(p.stats, 0, (size_t)p4p_gemm_tn_colsum_rows(p.M) * p.N * sizeof(float), st));
     }
-    return launch_tn_inner<EPI>(p, st);
+    return launch_tn_inner<EPI>(p, st, g_gemm_variant);
 }
 
+// variant: the tile configuration (0 = choose); the peeled launches below pass theirs down as an argument (the global switch is
+// only READ, by launch_tn)
 template <int EPI>
-static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
+static int launch_tn_inner(const GemmParams& p, hipStream_t st, int variant) {
     constexpr bool STATS = EPI == EPI_BF16_ROWGROUP || EPI == EPI_BF16_STATS;
-    int v = g_gemm_variant;
+    int v = variant;
     const bool fits_tn4 = p.N % 256 == 0 && (long long)ceil_div(p.M, 256) * (p.N / 256) >= 256 &&
                           (unsigned long long)p.M * p.K * 2 < (1ull << 32) && (unsigned long long)p.N * p.K * 2 < (1ull << 32);
     if (STATS) {
@@ -156,11 +175,8 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
                 if (EPI == EPI_F32_RESID && p.rowgrp) b.rowgrp = p.rowgrp + ro * p.N;          // second residual
                 if (p.pre) b.pre = p.pre + ro * p.N;
                 if (EPI == EPI_BF16_DGELU && p.stats) b.stats = p.stats + (size_t)2 * (a.M / 256) * p.N;   // rows behind the main part's
-                const int saved = g_gemm_variant;
-                g_gemm_variant = v;                                     // main part: no further peeling (rem == 0)
-                int rc = launch_tn_inner<EPI>(a, st);
-                g_gemm_variant = 6;                                     // 64x64 tiles: 4x more workgroups for the short tail
-                if (!rc) {
+                int rc = launch_tn_inner<EPI>(a, st, v);               // main part: no further peeling (rem == 0)
+                if (!rc) {                                              // tail: 64x64 tiles (variant 6), 4x more workgroups for the short launch
                     int splits = 1;
                     if constexpr (EPI == EPI_BF16 || EPI == EPI_F32_RESID) {
                         if (p.K >= 1536 && p.N % 4 == 0) {    // long K: slices of 768 (or 512) columns
@@ -170,16 +186,11 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
                     }
                     if (splits > 1) {
                         const size_t plane = (size_t)b.M * b.N, need = plane * splits;
-                        if (need > g_splitk_ws_floats) {
-                            if (g_splitk_ws) P4P_HIP(hipFree(g_splitk_ws));
-                            g_splitk_ws = nullptr;
-                            g_splitk_ws_floats = 0;
-                            P4P_HIP(hipMalloc(&g_splitk_ws, need * sizeof(float)));
-                            g_splitk_ws_floats = need;
-                        }
+                        float* ws = nullptr;
+                        if (splitk_workspace(need, &ws)) return 2;
                         GemmParams c = b;
                         c.K = p.K / splits;
-                        c.out = g_splitk_ws;
+                        c.out = ws;
                         c.bias = nullptr;
                         c.resid = nullptr;
                         c.rowgrp = nullptr;
@@ -187,15 +198,14 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
                         hipLaunchKernelGGL((gemm_tn2_kernel<64, 64, 2, 2, EPI_F32_RESID, false, 0>), dim3(tiles, splits), dim3(256), 0, st, c);
                         P4P_LAUNCH_CHECK();
                         hipLaunchKernelGGL(splitk_finish_kernel, dim3(ceil_div((long long)plane / 4, 256)), dim3(256), 0, st,
-                                           g_splitk_ws, splits, (long long)plane, b.bias, b.resid,
+                                           ws, splits, (long long)plane, b.bias, b.resid,
                                            EPI == EPI_F32_RESID ? b.rowgrp : nullptr, b.out,
                                            EPI == EPI_F32_RESID ? 1 : 0, b.N);
                         P4P_LAUNCH_CHECK();
                     } else {
-                        rc = launch_tn_inner<EPI>(b, st);
+                        rc = launch_tn_inner<EPI>(b, st, 6);
                     }
                 }
-                g_gemm_variant = saved;
                 return rc;
             }
         }
@@ -242,7 +252,7 @@ static int launch_tn_inner(const GemmParams& p, hipStream_t st) {
             // every other tile configuration: plain launch, then one streaming pass for the column sums
             GemmParams q = p;
             q.stats = nullptr;
-            int rc = launch_tn_inner<EPI>(q, st);
+            int rc = launch_tn_inner<EPI>(q, st, v);
             if (!rc) rc = p4p_colsum_partial_bf16(p.out, p.stats, p.M, p.N, st);
             return rc;
         }

@@ -8,10 +8,16 @@ from . import _lib as L
 EPI_BF16, EPI_BF16_GELU, EPI_F32_RESID, EPI_BF16_DGELU, EPI_BF16_ROWGROUP, EPI_BF16_STATS = range(6)
 
 
-def _stream():
-    # the raw handle of torch's current HIP stream on the current device (torch.cuda.current_stream() builds a Stream object
-    # through four Python frames: 9 us per call, ~200 calls per step)
-    return L.ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+try:
+    _raw_stream, _cur_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+
+    def _stream():
+        # the raw handle of torch's current HIP stream on the current device (torch.cuda.current_stream() builds a Stream object
+        # through four Python frames: 9 us per call, ~200 calls per step)
+        return L.ctypes.c_void_p(_raw_stream(_cur_device()))
+except AttributeError:                                       # a torch that renamed the private hooks: the public, slower way
+    def _stream():
+        return L.ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def _chk(t, name, dtype=None, dims=None):
@@ -238,7 +244,8 @@ def attention_bwd(qkv, o, dout, lse, B, T, H, want_colsum=False):
     _chk(lse, 'lse', torch.float32, 3)
     D = o.shape[1]
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    # per-call workspace from torch's caching allocator (stream-ordered): delta, or the dQ^T parking space of the T = 513 kernel
+    delta = torch.empty(L.call_int('p4p_attention_bwd_workspace', B, T, H), dtype=torch.float32, device=qkv.device)
     part = None
     if want_colsum:
         rows = L.call_int('p4p_attention_colsum_rows', B, T)

@@ -34,7 +34,18 @@ class FusedAdamW(torch.optim.Optimizer):
         a new tensor costs ~2 ms): a small ring of persistent pinned staging buffers per (dtype, size), each guarded by the event
         recorded behind its last copy (waited for only if the host is a whole ring ahead of the device)."""
         key = (host.dtype, host.numel())
-        ring = self._staging.setdefault(key, {'slots': [], 'next': 0})
+        ring = self._staging.get(key)
+        if ring is None:
+            # a new table size = a new set of parameters with gradients; the rings of sizes no longer in use would otherwise stay
+            # pinned for good.  Few sizes are live at a time (tensor table, chunk list, per-subset tables): keep the 6 most recent
+            while len(self._staging) >= 6:
+                old = self._staging.pop(next(iter(self._staging)))
+                for _, ev in old['slots']:
+                    if ev is not None:
+                        ev.synchronize()           # its last copy has left the pinned buffer before the buffer is freed
+            ring = self._staging[key] = {'slots': [], 'next': 0}
+        else:
+            self._staging[key] = self._staging.pop(key)      # most recently used last
         if len(ring['slots']) < 8:
             ring['slots'].append([torch.empty(host.numel(), dtype=host.dtype).pin_memory(), None])
             slot = ring['slots'][-1]

@@ -10,6 +10,10 @@
  *   - return 0 on success; non-zero = invalid argument (1) or HIP error (2), message from
  *     p4p_last_error() (thread local).  Nothing is launched when an argument check fails.
  *   - bf16 buffers are passed as void*.
+ *   - threading: ONE host thread at a time per process and ONE stream per device.  The switches (p4p_set_*) and the per-device
+ *     split-K scratch of p4p_gemm_tn_bf16 (a few MB, grown with hipMalloc on first use of a larger shape: the only allocation the
+ *     library makes) are unsynchronised process state; forward and backward of one model never run concurrently in the trainer
+ *     (autograd's backward thread takes over after the forward has returned), which is the case this library is written for.
  */
 #ifndef P4P_HIP_H
 #define P4P_HIP_H
@@ -19,9 +23,10 @@ extern "C" {
 #endif
 
 /* Bumped on every incompatible change of a signature below (2: p4p_clip_coef gained grad_scale, p4p_apf_group gained C;
- * 3: the version check itself; 4: p4p_layernorm_bwd gained dx_in; 5: p4p_set_reserved_cus / p4p_persistent_grid_size).  libp4p_hip.so is built separately from the Python package: the binding compares p4p_abi_version() with
+ * 3: the version check itself; 4: p4p_layernorm_bwd gained dx_in; 5: p4p_set_reserved_cus / p4p_persistent_grid_size;
+ * 6: p4p_attention_bwd's workspace is sized by p4p_attention_bwd_workspace and no library-owned scratch remains on that path).  libp4p_hip.so is built separately from the Python package: the binding compares p4p_abi_version() with
  * this constant when it loads the library and refuses a stale build. */
-#define P4P_ABI_VERSION 5
+#define P4P_ABI_VERSION 6
 int p4p_abi_version(void);
 const char* p4p_last_error(void);
 
@@ -99,8 +104,9 @@ int p4p_colreduce_f32(const float* part, float* out, int nrows, long long stride
 
 /* qkv [B*T,3D] bf16 (q|k|v, heads inside), out [B*T,D] bf16, lse2 [B,H,T] f32 (may be NULL for inference). */
 int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B, int T, int H, int D, float scale, void* stream);
-/* dqkv [B*T,3D] bf16 <- gradients; delta [B,H,T] f32 workspace (its contents after the call are unspecified: the kernels for
-   T = 65 / 129 / 257 -- one fused launch for dq, dk, dv, csrc/attention_fused.h -- do not use it).  Same arithmetic contract for
+/* dqkv [B*T,3D] bf16 <- gradients; delta: f32 workspace of p4p_attention_bwd_workspace(B,T,H) floats (>= B*H*T; the one-kernel
+   backward at T = 513, csrc/attention_fused2.h, parks its half-finished dQ^T chains there, 139 KB per workgroup; contents after the
+   call are unspecified).  The workspace belongs to the call: two calls in flight on different streams need two workspaces.  Same arithmetic contract for
    every T (P and dS rounded to bf16 where they enter a product, fp32 accumulation, no atomics: bitwise reproducible); which
    kernels run depends on T only.  colsum_partial (may be NULL):
    [p4p_attention_colsum_rows(B,T)][3D] f32 per-wave column sums of dqkv, written by the same kernels; reduced with
@@ -108,6 +114,7 @@ int p4p_attention_fwd(const void* qkv, void* out, float* lse2, int B, int T, int
 int p4p_attention_bwd(const void* qkv, const void* o, const void* dout, const float* lse2, float* delta, void* dqkv,
                       float* colsum_partial, int B, int T, int H, int D, float scale, void* stream);
 int p4p_attention_colsum_rows(int B, int T);
+long long p4p_attention_bwd_workspace(int B, int T, int H);
 
 /* ---- streaming helpers ----------------------------------------------------------------------------- */
 

@@ -61,3 +61,32 @@ def test_wgrad_split_heuristic_is_sane():
     for M, N, K in [(65792, 3072, 768), (65792, 768, 768), (2056, 576, 192), (64, 128, 128)]:
         s = lib.p4p_wgrad_splits(M, N, K)
         assert 1 <= s <= 64 and s <= (M + 63) // 64
+
+
+def test_every_declared_symbol_has_its_prototype_bound():
+    """the binding takes restype / argtypes of every entry point from include/p4p_hip.h, so a Python int
+    reaches a `long long` parameter as 64 bits and a float cannot land in an integer slot."""
+    lib = _lib.lib()
+    sigs = _lib.declared_signatures()
+    assert sorted(sigs) == _lib.declared_symbols()
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)
+        assert fn.restype is res and list(fn.argtypes) == args, name
+    assert sigs['p4p_last_error'] == (ctypes.c_char_p, [])
+    assert sigs['p4p_sum_slabs_f32'][1] == [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
+    assert sigs['p4p_clip_coef'][1][2:4] == [ctypes.c_float, ctypes.c_float]
+    assert sigs['p4p_pos_mlp0_bwd_rows'] == (ctypes.c_int, [ctypes.c_longlong])
+    assert len(sigs['p4p_gemm_tn_bf16'][1]) == 14 and len(sigs['p4p_embed_stage1_bwd'][1]) == 27
+
+
+def test_arguments_that_do_not_fit_the_prototype_are_refused():
+    # a 64-bit count passes through a `long long` parameter unharmed (bare Python int, no i64() wrapper) ...
+    assert _lib.call_int('p4p_pos_mlp0_bwd_rows', 5_000_000_000) > 1_000_000
+    # ... a float in an int slot and a wrong argument count are errors, not silent reinterpretations
+    with pytest.raises(_lib.P4PError, match='prototype'):
+        _lib.call_int('p4p_wgrad_splits', 1024.0, 128, 128)
+    with pytest.raises(TypeError):
+        _lib.call_int('p4p_wgrad_splits', 1024, 128)
+    # an export the header does not declare is not callable through the binding
+    with pytest.raises((_lib.P4PError, AttributeError)):
+        _lib.call('p4p_not_an_entry_point')

@@ -564,6 +564,37 @@ def test_attention_backward_fused_t513_against_the_kernels_it_replaces(B, H):
         assert (new[sl].float() - qr.grad).abs().max().item() <= 3e-2 * sc
 
 
+def test_attention_backward_t513_workspace_belongs_to_the_call():
+    """the fused T = 513 backward parked its dQ^T chains in a function-static, library-owned hipMalloc that every
+    stream shared.  The parking space is now the caller's workspace (p4p_attention_bwd_workspace floats, taken per call from
+    torch's stream-ordered allocator): two backward calls in flight on two streams, each walking 256 workgroups' worth of pairs,
+    give the bits of the same calls run one after the other."""
+    from p4p_amd import _lib
+    B, T, H, D = 64, 513, 12, 768
+    assert _lib.call_int('p4p_attention_bwd_workspace', B, T, H) > B * H * T          # the parking space, not just delta
+    assert _lib.call_int('p4p_attention_bwd_workspace', B, 257, H) == B * H * 257
+    g = torch.Generator(device=DEV).manual_seed(11)
+    ins = []
+    for _ in range(2):
+        qkv = torch.randn(B * T, 3 * D, device=DEV, generator=g).bfloat16()
+        do = torch.randn(B * T, D, device=DEV, generator=g).bfloat16()
+        o, lse = ops.attention_fwd(qkv, B, T, H)
+        ins.append((qkv, o, do, lse))
+    want = [ops.attention_bwd(q, o, do, lse, B, T, H).clone() for q, o, do, lse in ins]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = [[], []]
+    for rep in range(4):                                   # interleaved enqueue: the two streams' kernels overlap on the chip
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                q, o, do, lse = ins[i]
+                got[i].append(ops.attention_bwd(q, o, do, lse, B, T, H))
+    torch.cuda.synchronize()
+    for i in range(2):
+        for rep, x in enumerate(got[i]):
+            assert torch.equal(x, want[i]), f'stream {i}, launch {rep}: a concurrent call disturbed the parked dQ chains'
+
+
 @pytest.mark.parametrize('B,T,H', [(2, 2049, 3), (1, 1300, 2), (3, 513, 4)])
 def test_attention_forward_two_and_four_query_tiles_per_wave_are_bit_identical(B, T, H):
     """attn_fwd_q_kernel<2> / <4>: the number of 16-query tiles a wave carries is a scheduling choice (round 4: taken by how many times the

@@ -21,7 +21,7 @@ st = ops._stream()
 
 def run():
     dqkv = torch.full_like(qkv, float('nan'))
-    delta = torch.full((B, H, T), float('nan'), dtype=torch.float32, device=DEV)
+    delta = torch.full((L.call_int('p4p_attention_bwd_workspace', B, T, H),), float('nan'), dtype=torch.float32, device=DEV)
     part = None
     if COLSUM:
         rows = L.call_int('p4p_attention_colsum_rows', B, T)

@@ -19,7 +19,9 @@ dout = torch.randn(B * T, D, generator=g).to(torch.bfloat16).cuda()
 out = torch.empty(B * T, D, dtype=torch.bfloat16, device='cuda')
 dqkv = torch.empty_like(qkv)
 lse = torch.zeros(B * H * T, dtype=torch.float32, device='cuda')
-delta = torch.zeros(B * H * T, dtype=torch.float32, device='cuda')
+lib.p4p_attention_bwd_workspace.restype = ctypes.c_longlong
+park = int(lib.p4p_attention_bwd_workspace(B, T, H))        # the kernel parks dQ^T chains here; the stamps go behind them
+delta = torch.zeros(park + B * H * 32, dtype=torch.float32, device='cuda')
 cs = torch.zeros(B * 9 * 4 * 3 * D, dtype=torch.float32, device='cuda') if os.environ.get('F2_CS') else None
 ptr = lambda t: ctypes.c_void_p(0 if t is None else t.data_ptr())
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -28,7 +30,7 @@ for _ in range(3):
     assert lib.p4p_attention_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(delta), ptr(dqkv), ptr(cs), B, T, H, D,
                                  ctypes.c_float(0.125), st) == 0
 torch.cuda.synchronize()
-raw = delta.view(torch.int64)[:B * H * 16].view(B * H, 16).cpu().double()
+raw = delta[park:].view(torch.int64)[:B * H * 16].view(B * H, 16).cpu().double()
 rel = raw - raw[:, 0:1]
 names = ['start', 'Q / dO DMAs issued, odd pair', 'images landed + barrier', 'delta + odd key phase', 'half 0: K chunks, K^T frags', 'half 0: 17 query tiles',
          'half 0: dK / dV out', 'half 1: K chunks, K^T frags', 'half 1: 17 query tiles', 'half 1: dK / dV out (end)']
