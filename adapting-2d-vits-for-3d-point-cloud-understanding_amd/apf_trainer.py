@@ -83,11 +83,10 @@ class APFTrainer(Pix4PointTrainer):
         self.model.to(self.device)
         broadcast_parameters(self.model)
         # one bucket (only the head and the point encoder train: quirk 10); the frozen parameters are remembered so that one
-        # unfrozen later is refused instead of silently staying local to its rank; CUs for RCCL as in ddp.build_reducer
+        # unfrozen later is refused instead of silently staying local to its rank.  No CUs are reserved for RCCL here: the one
+        # all-reduce is launched AND waited for inside finish(), after the backward -- no kernel of this library runs beside it
         self.reducer = (GradReducer([[p for p in self.model.parameters() if p.requires_grad]],
                                     outside=list(self.model.parameters())) if self.distributed else None)
-        if self.reducer is not None:
-            self.reducer.reserve_cus()
 
     # ---- reference :84-146
     def _init_datasets(self) -> None:
@@ -171,8 +170,6 @@ class APFTrainer(Pix4PointTrainer):
     # ---- reference :205-247: the scheduler is stepped with the epoch index after the test phase
     def train(self) -> None:
         best_acc = 0.0
-        if self.reducer is not None:
-            self.reducer.reserve_cus()
         try:
             for epoch in range(self.train_config['epochs']):
                 if self.rank == 0:

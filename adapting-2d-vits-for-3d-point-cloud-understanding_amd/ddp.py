@@ -72,36 +72,42 @@ class GradReducer:
         inside = {id(p) for p in params}
         self._outside = [p for p in (outside or []) if id(p) not in inside]
         self._stale_zeroed = 0             # regions finish() had to zero (a block whose backward did not write): diagnostic
-        self.reserved_cus = None           # what reserve_cus() told the library to leave to RCCL (None: untouched)
-        self._cus_before = None            # the library's value before reserve_cus(): release_cus() puts it back
+        self.reserved_cus = None           # the PLAN of reserve_cus(): CUs left to RCCL inside the backward window (None: none)
+        self._cus_before = None            # inside the window: the library's value before backward_begins(), restored by finish()
 
     # -- compute units for the collectives ---------------------------------------------------
     def reserve_cus(self, reserved_cus=None):
-        """Size this library's one-round grids to CUs - r while this reducer is in use (planned_reserved_cus decides r: an
-        explicit value, P4P_RESERVED_CUS, or RCCL's channel bound when the group's backend is RCCL and world > 1; host-side
-        backends such as gloo hold no CUs and reserve nothing).  The setting is library-global and changes the summation order
-        of the weight-gradient M-splits (not the forward), so it is restored by release_cus() -- trainers call that in
-        train()'s finally; a model evaluated afterwards runs on all CUs again.  Returns the value set, None if untouched."""
+        """PLAN to size this library's one-round grids to CUs - r while collectives can be in flight (planned_reserved_cus decides
+        r: an explicit value, P4P_RESERVED_CUS, or RCCL's channel bound when the group's backend is RCCL and world > 1; host-side
+        backends such as gloo hold no CUs and reserve nothing).  The library-global switch is only SET inside the window in which
+        an all-reduce can overlap this library's kernels -- from backward_begins() (the encoder's backward calls it) to the end
+        of finish(): the forward pass and the optimizer step never run next to a collective and keep all CUs (measured on one
+        GPU, N=1024 step: grids of CUs - 8 alone cost 1.5 ms of 51.7, tools/contention_profile.py).  The setting changes the
+        summation order of the weight-gradient M-splits (not the forward).  release_cus() drops the plan; trainers call it in
+        train()'s finally.  Returns the planned value, None if there is none."""
         if reserved_cus is None:
             reserved_cus = getattr(self, '_cus_asked', None)            # a later call (train() after release_cus()) repeats the first
         self._cus_asked = reserved_cus
-        r = planned_reserved_cus(self.world, reserved_cus, _backend_of(self.group))
-        if r is None:
-            return None
-        from . import ops
-        before = ops.set_reserved_cus(r)
-        if self._cus_before is None:
-            self._cus_before = before
-        self.reserved_cus = r
-        return r
+        self.reserved_cus = planned_reserved_cus(self.world, reserved_cus, _backend_of(self.group))
+        return self.reserved_cus
 
-    def release_cus(self):
-        """Undo reserve_cus(): the library goes back to the value it had before this reducer changed it."""
+    def backward_begins(self):
+        """Called where the overlap window opens (functional._EncoderFn.backward): from here to finish() the buckets' all-reduces
+        run beside this library's kernels."""
+        if self.reserved_cus is not None and self._cus_before is None:
+            from . import ops
+            self._cus_before = ops.set_reserved_cus(self.reserved_cus)
+
+    def _window_closes(self):
         if self._cus_before is not None:
             from . import ops
             ops.set_reserved_cus(self._cus_before)
             self._cus_before = None
-            self.reserved_cus = None
+
+    def release_cus(self):
+        """Drop the plan (and close the window if a step was abandoned inside it): the library is where it was before."""
+        self._window_closes()
+        self.reserved_cus = None
 
     def register_block(self, params: Iterable[torch.nn.Parameter]):
         """Declare one block (a run of consecutive parameters of one bucket that the backward writes as a unit): finish()
@@ -192,6 +198,7 @@ class GradReducer:
         self._handles.clear()
         self._launched.clear()
         self._have = [0] * len(self.buckets)
+        self._window_closes()              # every collective has been waited for: the optimizer and the next forward get all CUs
         if average and self.world > 1:
             self.flat.mul_(self.grad_scale)
 
@@ -204,25 +211,34 @@ class GradReducer:
              'collectives_launched': self.collectives_launched}
         if self.reserved_cus is not None and self.flat.is_cuda:
             from . import ops
+            old = ops.set_reserved_cus(self.reserved_cus)
             cus, grid = ops.device_cu_count(), ops.persistent_grid_size()
+            ops.set_reserved_cus(old)
+            d['persistent_grid_in_backward'] = grid
             d['reserved_cus_effective'] = (cus - grid) if (cus > 0 and grid > 0) else None      # None: persistent kernels off (r < 0)
         return d
 
     def zero_grad(self):
         """Only the tail bucket accumulates (autograd adds into its views); the block buckets are overwritten by the
         encoder's backward (finish() zeroes any registered block that was NOT written in a step)."""
+        self._window_closes()              # a step abandoned between backward and finish() must not leave the next forward on CUs - r
         s, e = self.buckets[-1]
         self.flat[s:e].zero_()
 
 
-RCCL_MAX_CHANNELS = 32
+RCCL_MAX_CHANNELS = 8
 
 
 def configure_rccl_env(max_channels=RCCL_MAX_CHANNELS):
     """Call BEFORE init_process_group('nccl'): bounds the workgroups (= channels, one CU each) an RCCL collective may occupy, so
-    that the number of CUs to leave to it is KNOWN (reserve_cus_for_collectives).  A ViT-B gradient set is 345 MB per step behind
-    ~40 ms of backward: 32 channels are far more than the all-reduce needs to stay hidden.  An NCCL_MAX_NCHANNELS the user has set
-    is respected."""
+    that the number of CUs to leave to it is KNOWN (planned_reserved_cus).  What the gradient exchange needs is little: 345 MB
+    per step (ViT-B) spread over ~35 ms of backward, and the one bucket whose all-reduce is not covered by a later block (28 MB,
+    block 0) has the ~2.5 ms of the tokenizer's backward to finish in -- 20 GB/s of bus bandwidth, an eighth of what 8 channels
+    move.  What the channels COST is measured (one GPU, N=1024 step, grids of CUs - r and nothing else changed,
+    tools/contention_profile.py --no-park): r = 8 +1.6 ms, 16 +2.3, 24 / 32 +2.9 of 51.3 ms for the whole step, about two thirds
+    of that inside the backward window where the reservation applies.  Round 5: 8 (was 32).  bench.py --gpus N prints
+    allreduce_exposed_ms: if a real 8-GPU run shows the all-reduce exposed, raise it.  An NCCL_MAX_NCHANNELS the user has set is
+    respected."""
     os.environ.setdefault('NCCL_MAX_NCHANNELS', str(int(max_channels)))
     return int(os.environ['NCCL_MAX_NCHANNELS'])
 
@@ -245,8 +261,8 @@ def planned_reserved_cus(world, reserved_cus=None, backend=None):
     One-GPU rehearsal with r parked stand-in workgroups (tools/contention_rehearsal.py, N=1024 step, 51.4 ms alone): 72.2 ms
     with r = 8 and no remedy, 55.9 ms with all those grids on CUs - r (p4p_set_reserved_cus), 62.1 ms with a workgroup per
     tile / pair (r < 0: the weight gradients keep 256 splits).
-    Order: the explicit argument; P4P_RESERVED_CUS; world > 1 on RCCL ('nccl'): NCCL_MAX_NCHANNELS (configure_rccl_env: 32),
-    i.e. what RCCL can take at most (r = 8 and r = 32 cost the same: tile counts quantise alike); otherwise None -- world 1,
+    Order: the explicit argument; P4P_RESERVED_CUS; world > 1 on RCCL ('nccl'): NCCL_MAX_NCHANNELS (configure_rccl_env: 8),
+    i.e. what RCCL can take at most; otherwise None -- world 1,
     and host-side backends (gloo collectives run on the CPU and hold no CU), leave the library alone."""
     if reserved_cus is not None:
         return int(reserved_cus)

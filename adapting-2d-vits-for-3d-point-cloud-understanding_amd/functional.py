@@ -416,6 +416,8 @@ class _EncoderFn(torch.autograd.Function):
         dwork = torch.empty(M, D, dtype=torch.float32, device=dev) if L else None
         grads = [None] * (L * _BLOCK_PARAMS)
         sink = ctx.grad_sink
+        if sink is not None:
+            sink.backward_begins()          # data parallel: from here to finish() all-reduces run beside these kernels (CUs - r grids)
         for l in reversed(range(L)):
             n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b = bp[l * _BLOCK_PARAMS:(l + 1) * _BLOCK_PARAMS]
             xin, mean1, rstd1, ln1, qkv, att, lse, x1, mean2, rstd2, ln2, hpre, g = saved[l * 13:(l + 1) * 13]

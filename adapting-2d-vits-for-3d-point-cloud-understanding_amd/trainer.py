@@ -167,7 +167,7 @@ class Pix4PointTrainer:
     def train(self) -> None:
         best_acc = 0.0
         if self.reducer is not None:
-            self.reducer.reserve_cus()                  # CUs for RCCL while training (no-op if build_reducer's still holds)
+            self.reducer.reserve_cus()                  # the plan for the backward windows (build_reducer's, if still there)
         try:
             for epoch in range(getattr(self, 'start_epoch', 0), self.train_config['epochs']):      # > 0 after load_checkpoint
                 if self.rank == 0:

@@ -136,8 +136,6 @@ class ApfStepper:
         broadcast_parameters(self.model)
         self.reducer = (GradReducer([[p for p in self.model.parameters() if p.requires_grad]], outside=list(self.model.parameters()))
                         if distributed else None)
-        if self.reducer is not None:
-            self.reducer.reserve_cus()
         self.opt = FusedAdamW(self.model.parameters(), lr=5e-4, weight_decay=5e-2)
         self.crit = torch.nn.CrossEntropyLoss(label_smoothing=0.3)
 
@@ -557,8 +555,9 @@ def main():
     if getattr(stepper, 'reducer', None) is not None:
         from p4p_amd import ops as _ops
         ddp_info = dict(stepper.reducer.describe(), backend=dist.get_backend(), persistent_grid=_ops.persistent_grid_size())
-        log(f'rank {rank}: gradient buckets {ddp_info["buckets"]} ({ddp_info["total_bytes"] * 1e-6:.0f} MB in all), reserved CUs '
-            f'{ddp_info["reserved_cus"]}, persistent grid {ddp_info["persistent_grid"]}')
+        log(f'rank {rank}: gradient buckets {ddp_info["buckets"]} ({ddp_info["total_bytes"] * 1e-6:.0f} MB in all), CUs left to the '
+            f'collectives inside the backward window {ddp_info["reserved_cus"]} (persistent grid there '
+            f'{ddp_info.get("persistent_grid_in_backward")}, elsewhere {ddp_info["persistent_grid"]})')
     log(f'rank {rank}/{world}: model built, warm-up {args.warmup} steps')
     for _ in range(args.warmup):
         stepper.step(*batch)

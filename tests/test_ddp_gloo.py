@@ -179,8 +179,8 @@ def test_reserved_cu_plan_follows_backend_and_environment(monkeypatch):
     assert planned_reserved_cus(1, None, 'nccl') is None            # world 1: the library is left alone
     assert planned_reserved_cus(8, None, 'gloo') is None            # host-side collectives hold no CU
     assert planned_reserved_cus(8, None, None) is None
-    assert planned_reserved_cus(8, None, 'nccl') == 32              # RCCL's channel bound (configure_rccl_env default)
-    assert planned_reserved_cus(8, None, 'cuda:nccl,cpu:gloo') == 32
+    assert planned_reserved_cus(8, None, 'nccl') == 8               # RCCL's channel bound (configure_rccl_env default)
+    assert planned_reserved_cus(8, None, 'cuda:nccl,cpu:gloo') == 8
     monkeypatch.setenv('NCCL_MAX_NCHANNELS', '16')
     assert planned_reserved_cus(8, None, 'nccl') == 16
     monkeypatch.setenv('P4P_RESERVED_CUS', '8')
@@ -188,22 +188,34 @@ def test_reserved_cu_plan_follows_backend_and_environment(monkeypatch):
     assert planned_reserved_cus(8, 0, 'nccl') == 0                  # the explicit argument wins
 
 
-def test_reserved_cus_are_a_handle_that_release_restores():
-    """building a reducer must not leave the process on CUs - 32 for good."""
+def test_reserved_cus_are_set_only_inside_the_backward_window():
+    """building a reducer must not leave the process on CUs - 32 for good.  The reservation is a PLAN; the
+    library-global switch is set from backward_begins() (the encoder's backward) to the end of finish() -- the only span in which
+    an all-reduce runs beside this library's kernels -- and a step abandoned inside the window is repaired by zero_grad()."""
     from p4p_amd import ops
     lin = torch.nn.Linear(4, 4)
     start = ops.set_reserved_cus(8)
     try:
         red = GradReducer([list(lin.parameters())])
-        assert red.reserve_cus() is None and red.reserved_cus is None       # world 1, no request: untouched
-        assert ops.set_reserved_cus(8) == 8
+        assert red.reserve_cus() is None and red.reserved_cus is None       # world 1, no request: no plan
+        red.backward_begins()
+        assert ops.set_reserved_cus(8) == 8                                 # ... and no window
         assert red.reserve_cus(24) == 24 and red.reserved_cus == 24
-        assert red.reserve_cus() == 24                                      # a later call repeats the first request ...
-        red.release_cus()
-        assert red.reserved_cus is None and ops.set_reserved_cus(8) == 8    # ... and release puts back what was there BEFORE it
-        red.release_cus()                                                   # idempotent
+        assert ops.set_reserved_cus(8) == 8                                 # a plan does not touch the library (forward: all CUs)
+        lin(torch.ones(2, 4)).sum().backward()
+        red.backward_begins()
+        assert ops.set_reserved_cus(24) == 24                               # inside the window
+        red.backward_begins()                                               # idempotent: the value to restore is not overwritten
+        red.finish()
+        assert ops.set_reserved_cus(8) == 8                                 # finish() puts back what was there before the window
+        red.backward_begins()
+        red.zero_grad()                                                     # a step abandoned before finish(): the next one starts clean
         assert ops.set_reserved_cus(8) == 8
-        assert red.reserve_cus() == 24                                      # train() after release_cus(): reserved again
-        red.release_cus()
+        assert red.reserve_cus() == 24                                      # a later call repeats the first request
+        red.backward_begins()
+        red.release_cus()                                                   # train()'s finally: plan dropped, window closed
+        assert red.reserved_cus is None and ops.set_reserved_cus(8) == 8
+        red.backward_begins()
+        assert ops.set_reserved_cus(8) == 8
     finally:
         ops.set_reserved_cus(start)

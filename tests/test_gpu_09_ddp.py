@@ -65,11 +65,13 @@ def _worker(rank, world, port, q, bucket_mb=None, reserved=None):
                 b.copy_(v)
 
         # The reserved CUs decide the M-split count (= summation order) of the weight-gradient GEMMs: the reference pass must run
-        # under the value the reducer is going to set, or "plain autograd" and "reducer" are two different computations.
+        # under the value the reducer sets inside its backward window, or "plain autograd" and "reducer" are two different
+        # computations (the forward is bit-identical under any r: test_persistent_kernels_on_fewer_cus_are_bit_identical).
         # gloo collectives hold no CU, so the default plan is None here; `reserved` exercises the CUs - r grids of a real RCCL run.
         plan = planned_reserved_cus(world, reserved, 'gloo')
         assert plan == reserved
         before = ops.set_reserved_cus(plan if plan is not None else 0)
+        assert before == 0
         # one unchecked warm-up step: stock-torch ops of the head (hipBLASLt Linear, MIOpen BatchNorm1d) settle on an algorithm
         torch.nn.functional.cross_entropy(model(pts, start), labels).backward()
         model.zero_grad(set_to_none=True)
@@ -83,9 +85,11 @@ def _worker(rank, world, port, q, bucket_mb=None, reserved=None):
         local = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
         model.zero_grad(set_to_none=True)
         restore_buffers()
+        ops.set_reserved_cus(0)                                 # from here on the reducer alone decides
 
         red = build_reducer(model, bucket_mb=bucket_mb, reserved_cus=reserved)
         assert red.reserved_cus == plan and len(red.buckets) == (2 if bucket_mb else 3)      # 2 blocks (+ tail); merged when asked
+        assert ops.set_reserved_cus(0) == 0                     # a plan, not a setting: the forward keeps all CUs
         opt = torch.optim.AdamW(model.get_param_groups(), lr=1e-3, weight_decay=5e-2, fused=True)
         red.zero_grad()
         red.flat.fill_(float('nan'))                            # the block buckets are OVERWRITTEN by the backward kernels ...
@@ -93,7 +97,10 @@ def _worker(rank, world, port, q, bucket_mb=None, reserved=None):
         F._CAPTURE_BWD = cap2 = {}
         torch.nn.functional.cross_entropy(model(pts, start), labels).backward()
         F._CAPTURE_BWD = None
+        if plan is not None:                                    # inside the backward window the library runs on CUs - plan ...
+            assert ops.persistent_grid_size() == ops.device_cu_count() - plan
         red.finish()
+        assert ops.persistent_grid_size() == ops.device_cu_count()      # ... and finish() gives them back
         same_upstream = torch.equal(cap1['block_dout'][1], cap2['block_dout'][1])      # top block's incoming gradient, both passes
 
         want = {}
@@ -139,9 +146,8 @@ def _worker(rank, world, port, q, bucket_mb=None, reserved=None):
             g = [torch.zeros_like(p.data) for _ in range(world)]
             dist.all_gather(g, p.data)
             assert torch.equal(g[0], g[1]), f'{n} diverged across ranks'
-        # the reservation is a handle: releasing it puts the library back where it was before build_reducer
         red.release_cus()
-        assert ops.set_reserved_cus(before) == (plan if plan is not None else 0)
+        assert red.reserved_cus is None and ops.set_reserved_cus(0) == 0
         q.put((rank, 'ok', worst[0], same_upstream))
     except Exception:                                       # pragma: no cover
         import traceback
