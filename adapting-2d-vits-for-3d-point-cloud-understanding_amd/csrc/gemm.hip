@@ -480,6 +480,55 @@ extern "C" int p4p_sum_slabs_f32(const float* slabs, float* out, long long n, in
     return 0;
 }
 
+// ---- several slab sums in ONE launch (round 5).  The weight-gradient GEMM of a ViT block leaves 64-66 MB of slabs per matrix and the
+// sum above ran once per matrix: 20.7 us for 67 MB in + 7 MB out (3.6 TB/s: a launch this short never reaches the streaming rate),
+// 54 launches = 1.1 ms per step.  The four matrices of a block are summed together at the end of the block's backward instead.
+#define P4P_SLAB_SUM_MAX 8
+struct SlabSumItem { const float* slabs; float* out; long long n; int nslabs; float beta; int block0; int pad; };
+struct SlabSumBatch { SlabSumItem it[P4P_SLAB_SUM_MAX]; int count; };
+__global__ __launch_bounds__(256) void reduce_slabs_multi_kernel(SlabSumBatch b) {
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < P4P_SLAB_SUM_MAX; ++j)
+        if (j < b.count && (int)blockIdx.x >= b.it[j].block0) i = j;
+    const SlabSumItem& it = b.it[i];
+    const long long n = it.n;
+    long long e = ((long long)(blockIdx.x - it.block0) * 256 + threadIdx.x) * 4;
+    if (e >= n) return;
+    const float* q = it.slabs + e;                       // the additions keep the order 0, 1, .. of reduce_slabs_kernel: bit-identical
+    f32x4 s = *reinterpret_cast<const f32x4*>(q);
+    const int splits = it.nslabs;
+    int k = 1;
+    for (; k + 3 < splits; k += 4) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(q + (size_t)k * n), a1 = *reinterpret_cast<const f32x4*>(q + (size_t)(k + 1) * n);
+        const f32x4 a2 = *reinterpret_cast<const f32x4*>(q + (size_t)(k + 2) * n), a3 = *reinterpret_cast<const f32x4*>(q + (size_t)(k + 3) * n);
+        s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(q + (size_t)k * n);
+    if (it.beta != 0.f) s += it.beta * *reinterpret_cast<const f32x4*>(it.out + e);
+    *reinterpret_cast<f32x4*>(it.out + e) = s;
+}
+// descs: HOST array of n records {const float* slabs; float* out; long long n; int nslabs; float beta} (32 bytes each, n <= 8)
+struct P4PSlabSum { const float* slabs; float* out; long long n; int nslabs; float beta; };
+extern "C" int p4p_sum_slabs_multi(const void* descs, int n, void* stream) {
+    P4P_CHECK(descs && n >= 1 && n <= P4P_SLAB_SUM_MAX, "p4p_sum_slabs_multi: 1 .. %d records (n=%d)", P4P_SLAB_SUM_MAX, n);
+    const P4PSlabSum* d = reinterpret_cast<const P4PSlabSum*>(descs);
+    SlabSumBatch b = {};
+    long long blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        P4P_CHECK(d[i].slabs && d[i].out && d[i].n >= 4 && d[i].n % 4 == 0 && d[i].nslabs >= 1, "p4p_sum_slabs_multi: record %d: bad arguments (n=%lld, nslabs=%d)", i, d[i].n, d[i].nslabs);
+        P4P_CHECK(((reinterpret_cast<size_t>(d[i].slabs) | reinterpret_cast<size_t>(d[i].out)) & 15) == 0, "p4p_sum_slabs_multi: record %d: 16-byte alignment", i);
+        b.it[i].slabs = d[i].slabs; b.it[i].out = d[i].out; b.it[i].n = d[i].n; b.it[i].nslabs = d[i].nslabs; b.it[i].beta = d[i].beta;
+        b.it[i].block0 = (int)blocks;
+        blocks += ceil_div(d[i].n / 4, 256);
+        P4P_CHECK(blocks < (1ll << 31), "p4p_sum_slabs_multi: grid limit");
+    }
+    b.count = n;
+    hipLaunchKernelGGL(reduce_slabs_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, b);
+    P4P_LAUNCH_CHECK();
+    return 0;
+}
+
 static bool wgrad_use_v3(int M, int N, int K) { return N % W3_BN == 0 && K % W3_BK == 0 && M >= 4096; }
 static int g_wgrad_wide = 2;      // 0: 256x128 tiles, 1: 256x256, 2: 256x256 with the hand-interleaved issue order
 extern "C" int p4p_set_wgrad_wide(int v) { int o = g_wgrad_wide; g_wgrad_wide = v; return o; }
@@ -511,6 +560,36 @@ extern "C" int p4p_wgrad_splits(int M, int N, int K) {
     return want;
 }
 
+// the GEMM of p4p_gemm_wgrad_bf16 WITHOUT its slab sum (ring kernel shapes only): slabs [p4p_wgrad_slab_count(M,N,K)][N][K] are left
+// in `workspace` for a later p4p_sum_slabs_multi.  p4p_wgrad_slab_count returns 0 for shapes the ring kernel does not take.
+extern "C" int p4p_wgrad_slab_count(int M, int N, int K) {
+    return wgrad_use_v3(M, N, K) ? ceil_div(ceil_div(M, 32), wgrad3_steps_per_split(M, N, K)) : 0;
+}
+static int launch_wgrad3(const void* G, const void* A, float* workspace, int M, int N, int K, hipStream_t st, int* splits_out) {
+    W3Params q;
+    q.G = (const __bf16*)G; q.A = (const __bf16*)A; q.M = M; q.N = N; q.K = K;
+    q.steps_per_split = wgrad3_steps_per_split(M, N, K);
+    const int splits3 = ceil_div(ceil_div(M, 32), q.steps_per_split);
+    q.out = workspace;
+    const bool prof = p4p_prof_begin(1, 2.0 * M * N * K, st);
+    if (wgrad3_wide(K) && (g_wgrad_wide & 3) == 2)
+        hipLaunchKernelGGL((gemm_wgrad3_kernel<256, true>), dim3((N / W3_BN) * (K / 256) * splits3), dim3(512), 0, st, q);
+    else if (wgrad3_wide(K))
+        hipLaunchKernelGGL(gemm_wgrad3_kernel<256>, dim3((N / W3_BN) * (K / 256) * splits3), dim3(512), 0, st, q);
+    else
+        hipLaunchKernelGGL(gemm_wgrad3_kernel<128>, dim3((N / W3_BN) * (K / W3_BK) * splits3), dim3(256), 0, st, q);
+    if (prof) p4p_prof_end(st);
+    P4P_LAUNCH_CHECK();
+    *splits_out = splits3;
+    return 0;
+}
+extern "C" int p4p_gemm_wgrad_slabs_bf16(const void* G, const void* A, float* workspace, int M, int N, int K, void* stream) {
+    P4P_CHECK(G && A && workspace, "p4p_gemm_wgrad_slabs_bf16: null pointer");
+    P4P_CHECK(wgrad_use_v3(M, N, K), "p4p_gemm_wgrad_slabs_bf16: M=%d N=%d K=%d is not a ring-kernel shape (p4p_wgrad_slab_count is 0)", M, N, K);
+    int splits3 = 0;
+    return launch_wgrad3(G, A, workspace, M, N, K, (hipStream_t)stream, &splits3);
+}
+
 // workspace: splits*(N*K + N) floats.  dbias (may be null) = beta*dbias + column sums of G, from the same pass.
 extern "C" int p4p_gemm_wgrad_bf16(const void* G, const void* A, float* dW, float* dbias, float* workspace, int M, int N,
                                    int K, float beta, void* stream) {
@@ -520,20 +599,8 @@ extern "C" int p4p_gemm_wgrad_bf16(const void* G, const void* A, float* dW, floa
     hipStream_t st = (hipStream_t)stream;
     if (wgrad_use_v3(M, N, K)) {
         P4P_CHECK(workspace, "p4p_gemm_wgrad_bf16: workspace required");
-        W3Params q;
-        q.G = (const __bf16*)G; q.A = (const __bf16*)A; q.M = M; q.N = N; q.K = K;
-        q.steps_per_split = wgrad3_steps_per_split(M, N, K);
-        int splits3 = ceil_div(ceil_div(M, 32), q.steps_per_split);
-        q.out = workspace;
-        const bool prof = p4p_prof_begin(1, 2.0 * M * N * K, st);
-        if (wgrad3_wide(K) && (g_wgrad_wide & 3) == 2)
-            hipLaunchKernelGGL((gemm_wgrad3_kernel<256, true>), dim3((N / W3_BN) * (K / 256) * splits3), dim3(512), 0, st, q);
-        else if (wgrad3_wide(K))
-            hipLaunchKernelGGL(gemm_wgrad3_kernel<256>, dim3((N / W3_BN) * (K / 256) * splits3), dim3(512), 0, st, q);
-        else
-            hipLaunchKernelGGL(gemm_wgrad3_kernel<128>, dim3((N / W3_BN) * (K / W3_BK) * splits3), dim3(256), 0, st, q);
-        if (prof) p4p_prof_end(st);
-        P4P_LAUNCH_CHECK();
+        int splits3 = 0;
+        if (launch_wgrad3(G, A, workspace, M, N, K, st, &splits3)) return 2;
         long long n = (long long)N * K;
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(ceil_div(n / 4, 256)), dim3(256), 0, st, workspace, dW, n, splits3,
                            beta);

@@ -16,6 +16,8 @@ from . import ops
 # statement can be checked LINK BY LINK against the pipeline's own upstream tensors (tests/test_gpu_03_matched_parity.py)
 _CAPTURE = None
 _CAPTURE_BWD = None        # tests only: a dict that the encoder's backward fills with every block's upstream gradient
+_DEFER_SLAB_SUMS = True       # encoder backward: the M-split slabs of a block's four weight-gradient GEMMs are summed by ONE launch at the end of the
+                              # block (ops.wgrad_flush) instead of one 20-us launch behind every GEMM; bit-identical (same order of additions)
 _FREE_DSTACK_EARLY = False    # encoder backward: copy the returned block-input gradient out of the slab stack so that the stack is freed before the
                               # embedding-stage backward.  Measured (tools/peak_memory.py): the step's peak is 29.0 GiB (N=1024) / 56.0 GiB (N=2048) of 288
                               # either way -- it is set inside the encoder backward, where the stack must exist -- so the copy is off
@@ -427,6 +429,7 @@ class _EncoderFn(torch.autograd.Function):
             # data parallel: the weight-gradient GEMMs write straight into the reducer's flat buffer (ddp.GradReducer)
             dst = sink.grad_views(bp[l * _BLOCK_PARAMS:(l + 1) * _BLOCK_PARAMS]) if (wg and sink is not None) else None
             out_w = (lambda j: dst[j]) if dst is not None else (lambda j: None)
+            wq = [] if _DEFER_SLAB_SUMS else None     # the block's four weight-gradient GEMMs queue their slab sums: ONE launch below
             # ---- mlp: x = x1 + fc2(gelu(fc1(ln2)))
             _, Wfc2T = _bf16_weights(fc2w, True)
             if wg:                           # fc1 bias gradient = column sums of dh, accumulated in the same epilogue
@@ -436,8 +439,8 @@ class _EncoderFn(torch.autograd.Function):
             _, Wfc1T = _bf16_weights(fc1w, True)
             dln2 = ops.gemm_tn(dh, Wfc1T, ops.EPI_BF16)
             if wg:
-                dfc2w, dfc2b = ops.gemm_wgrad(dxb, g, out=out_w(10)), dx_colsum
-                dfc1w = ops.gemm_wgrad(dh, ln2, out=out_w(8))
+                dfc2w, dfc2b = ops.gemm_wgrad(dxb, g, out=out_w(10), defer=wq), dx_colsum
+                dfc1w = ops.gemm_wgrad(dh, ln2, out=out_w(8), defer=wq)
             del dh
             _, dn2w, dn2b, dx_colsum = ops.layernorm_bwd(dln2, x1, mean2, rstd2, n2w.detach(), dx=dwork, dx_in=dx, dx_bf16=dxb,
                                                          want_dxsum=True)
@@ -445,7 +448,7 @@ class _EncoderFn(torch.autograd.Function):
             _, WprojT = _bf16_weights(projw, True)
             datt = ops.gemm_tn(dxb, WprojT, ops.EPI_BF16)
             if wg:
-                dprojw, dprojb = ops.gemm_wgrad(dxb, att, out=out_w(4)), dx_colsum
+                dprojw, dprojb = ops.gemm_wgrad(dxb, att, out=out_w(4), defer=wq), dx_colsum
             fuse_qkvb = T <= _FUSE_QKV_BIAS_MAXT
             if wg and fuse_qkvb:
                 dqkv, dqkvb = ops.attention_bwd(qkv, att, datt, lse, B, T, H, want_colsum=True)
@@ -455,7 +458,7 @@ class _EncoderFn(torch.autograd.Function):
             dln1 = ops.gemm_tn(dqkv, WqkvT, ops.EPI_BF16)
             if wg:
                 if fuse_qkvb:
-                    dqkvw = ops.gemm_wgrad(dqkv, ln1, out=out_w(2))
+                    dqkvw = ops.gemm_wgrad(dqkv, ln1, out=out_w(2), defer=wq)
                 else:
                     dqkvw, dqkvb = ops.gemm_wgrad(dqkv, ln1, out=out_w(2), want_bias=True)
             del dqkv, datt
@@ -463,6 +466,7 @@ class _EncoderFn(torch.autograd.Function):
             _, dn1w, dn1b, dx_colsum = ops.layernorm_bwd(dln1, xin, mean1, rstd1, n1w.detach(), dx=dx, dx_in=dwork, dx_bf16=dxb,
                                                          want_dxsum=True)
             if wg:
+                ops.wgrad_flush(wq)                  # before the bucket is handed to the all-reduce
                 grads[l * _BLOCK_PARAMS:(l + 1) * _BLOCK_PARAMS] = [dn1w, dn1b, dqkvw, dqkvb, dprojw, dprojb, dn2w, dn2b,
                                                                     dfc1w, dfc1b, dfc2w, dfc2b]
                 if sink is not None:

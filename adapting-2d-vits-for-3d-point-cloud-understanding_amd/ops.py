@@ -136,9 +136,26 @@ def _workspace(key, numel, device, dtype=torch.float32):
     return t
 
 
-def gemm_wgrad(g, a, out=None, beta=0.0, want_bias=False, bias_out=None):
+class _SlabSum(L.ctypes.Structure):          # include/p4p_hip.h: the record of p4p_sum_slabs_multi
+    _fields_ = [('slabs', L.ctypes.c_void_p), ('out', L.ctypes.c_void_p), ('n', L.ctypes.c_longlong),
+                ('nslabs', L.ctypes.c_int), ('beta', L.ctypes.c_float)]
+
+
+def wgrad_flush(defer):
+    """Sum the slabs of every weight gradient queued by gemm_wgrad(..., defer=queue) in one launch and empty the queue; the
+    `out` tensors those calls returned are valid afterwards (same bits as the undeferred call)."""
+    if not defer:
+        return
+    recs = (_SlabSum * len(defer))()
+    for r, (ws, out, n, nslabs, beta) in zip(recs, defer):
+        r.slabs, r.out, r.n, r.nslabs, r.beta = ws.data_ptr(), out.data_ptr(), n, nslabs, beta
+    L.call('p4p_sum_slabs_multi', recs, len(defer), _stream())
+    defer.clear()
+
+
+def gemm_wgrad(g, a, out=None, beta=0.0, want_bias=False, bias_out=None, defer=None):
     """dW[N,K] f32 = beta*dW + g[M,N]^T @ a[M,K]; with want_bias also returns the column sums of g
-    (the bias gradient), produced by the same kernel."""
+    (the bias gradient), produced by the same kernel.  defer: a list -- the result is complete only after wgrad_flush(list)."""
     _chk(g, 'g', torch.bfloat16, 2)
     _chk(a, 'a', torch.bfloat16, 2)
     M, N = g.shape
@@ -149,6 +166,15 @@ def gemm_wgrad(g, a, out=None, beta=0.0, want_bias=False, bias_out=None):
         out = torch.empty(N, K, dtype=torch.float32, device=g.device)
         beta = 0.0
     _chk(out, 'out', torch.float32, 2)
+    if defer is not None and not want_bias:
+        # slab sum deferred: the GEMM leaves its M-split slabs in a workspace of its own (one per queue position, persistent),
+        # wgrad_flush(defer) sums the slabs of everything queued in ONE launch (a ViT block's four matrices: 4 launches -> 1)
+        nslabs = L.call_int('p4p_wgrad_slab_count', M, N, K)
+        if nslabs > 0 and len(defer) < 8:
+            ws = _workspace(('wgrad_deferred', len(defer)), nslabs * N * K, g.device)
+            L.call('p4p_gemm_wgrad_slabs_bf16', L.ptr(g), L.ptr(a), L.ptr(ws), M, N, K, _stream())
+            defer.append((ws, out, N * K, nslabs, float(beta)))
+            return out
     splits = L.call_int('p4p_wgrad_splits', M, N, K)
     ws = _workspace('wgrad', splits * (N * K + N), g.device)
     if want_bias and bias_out is None:

@@ -24,7 +24,8 @@ extern "C" {
 
 /* Bumped on every incompatible change of a signature below (2: p4p_clip_coef gained grad_scale, p4p_apf_group gained C;
  * 3: the version check itself; 4: p4p_layernorm_bwd gained dx_in; 5: p4p_set_reserved_cus / p4p_persistent_grid_size;
- * 6: p4p_attention_bwd's workspace is sized by p4p_attention_bwd_workspace and no library-owned scratch remains on that path).  libp4p_hip.so is built separately from the Python package: the binding compares p4p_abi_version() with
+ * 6: p4p_attention_bwd's workspace is sized by p4p_attention_bwd_workspace and no library-owned scratch remains on that path;
+ * additions since (no bump): p4p_wgrad_slab_count, p4p_gemm_wgrad_slabs_bf16, p4p_sum_slabs_multi).  libp4p_hip.so is built separately from the Python package: the binding compares p4p_abi_version() with
  * this constant when it loads the library and refuses a stale build. */
 #define P4P_ABI_VERSION 6
 int p4p_abi_version(void);
@@ -76,6 +77,14 @@ int p4p_gemm_tn_colsum_rows(int M);
 int p4p_gemm_wgrad_bf16(const void* G, const void* A, float* dW, float* dbias, float* workspace, int M, int N, int K,
                         float beta, void* stream);
 int p4p_wgrad_splits(int M, int N, int K);
+/* The same GEMM with its slab sum deferred (round 5): p4p_gemm_wgrad_slabs_bf16 leaves [p4p_wgrad_slab_count(M,N,K)][N][K] f32 slabs
+ * in `workspace` (count 0: the shape is not taken, use p4p_gemm_wgrad_bf16), p4p_sum_slabs_multi sums the slabs of up to 8 matrices
+ * in ONE launch: out_i[e] = beta_i*out_i[e] + slabs_i[0][e] + slabs_i[1][e] + .. (the order of p4p_gemm_wgrad_bf16: bit-identical).
+ * descs: HOST array of n records {const float* slabs; float* out; long long n; int nslabs; float beta} (32 bytes each; n_i % 4 == 0).
+ * The four weight gradients of a ViT block (autograd of src/models/pix4point.py:254-255) are summed by one call per block. */
+int p4p_wgrad_slab_count(int M, int N, int K);
+int p4p_gemm_wgrad_slabs_bf16(const void* G, const void* A, float* workspace, int M, int N, int K, void* stream);
+int p4p_sum_slabs_multi(const void* descs, int n, void* stream);
 
 /* ---- LayerNorm (timm Block.norm1/norm2, VisionTransformer.norm; eps 1e-6) ------------------------- */
 

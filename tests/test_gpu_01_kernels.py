@@ -792,6 +792,32 @@ def test_gemm_wgrad_ring_kernel_exact_on_integer_data(M, N, K):
     assert torch.equal(acc, 2 * want)
 
 
+def test_gemm_wgrad_deferred_slab_sums_are_one_launch_and_bit_identical():
+    """Round 5: a ViT block's four weight-gradient GEMMs queue their slab sums (gemm_wgrad(..., defer=queue)) and one
+    p4p_sum_slabs_multi launch adds them at the end of the block -- the same additions in the same order as the sum that ran
+    behind every GEMM.  Shapes: the four of a ViT-B block at a ragged M, an accumulate (beta = 1) into an existing gradient, and
+    a shape the ring kernel does not take (it is computed at once and never enters the queue)."""
+    M, D = 4099 + 32 * 7, 768
+    g = torch.Generator().manual_seed(77)
+    shapes = [(3 * D, D), (D, D), (4 * D, D), (D, 4 * D), (64, 128)]
+    ops_in = [((torch.randn(M, N, generator=g) * 0.5).to(torch.bfloat16).to(DEV), torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV))
+              for N, K in shapes]
+    base = [torch.randn(N, K, generator=g).to(DEV) for N, K in shapes]
+    for beta in (0.0, 1.0):
+        want = [ops.gemm_wgrad(G, A, out=b.clone(), beta=beta) for (G, A), b in zip(ops_in, base)]
+        queue, got = [], []
+        for (G, A), b in zip(ops_in, base):
+            got.append(ops.gemm_wgrad(G, A, out=b.clone(), beta=beta, defer=queue))
+        assert len(queue) == 4                                  # the small shape did not queue
+        assert torch.equal(got[4], want[4])
+        if beta == 0.0:
+            assert not torch.equal(got[0], want[0])             # nothing has been summed yet
+        ops.wgrad_flush(queue)
+        assert queue == []
+        for x, y, (N, K) in zip(got, want, shapes):
+            assert torch.equal(x, y), (N, K, beta)
+
+
 @pytest.mark.parametrize('M,N,K', [(11009, 768, 256), (4099, 3072, 1024), (32771, 512, 128)])
 def test_gemm_wgrad_ring_kernel_never_reads_past_a_ragged_end(M, N, K):
     """Regression (round 2): with an ODD number (>= 5) of 32-row steps in the last M-split and M % 32 != 0 the unchecked
