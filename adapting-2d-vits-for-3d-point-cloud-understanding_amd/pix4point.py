@@ -141,7 +141,7 @@ class PointViT(nn.Module):
         if kinds and len(set(kinds)) == len(kinds) and x.dtype == torch.float32:
             return F.global_feat(x, kinds)             # one kernel each way (functional._GlobalFeatFn)
         # a pooling repeated in the configuration, or a non-fp32 stream: the stock-torch form of the same selection
-        pooled = {'cls': lambda: x[:, 0, :], 'max': lambda: x[:, 1:, :].amax(dim=1)}
+        pooled = {'cls': lambda: x[:, 0, :], 'max': lambda: x[:, 1:, :].max(dim=1).values}
         return torch.cat([pooled[k]() for k in kinds], dim=1)
 
     def get_trainable_params(self) -> Iterator[nn.Parameter]:
