@@ -257,12 +257,17 @@ static int bnc_tpr(int C) {            // gcd(C / 8, 256): a power of two
     while (g < 256 && t % (2 * g) == 0) g *= 2;
     return g;
 }
-template <bool BWD>
+// GSUM (backward only, round 5): the same pass also emits gsum[g][c] = sum over the k rows of group g of the bf16 values it writes (fp32
+// sum in row order, rounded once: the bits of group_sum_bf16_kernel on the finished tensor, without its 1.07-GB read).  A thread then
+// walks a CONTIGUOUS run of BNC_ROWS / (256 / tpr) rows (whole groups: the launcher checks the divisibility), a wave still reads one
+// full row per iteration.
+template <bool BWD, bool GSUM = false>
 __global__ __launch_bounds__(256) void bn_colwise_kernel(const __bf16* __restrict__ x, __bf16* __restrict__ y,
                                                          const __bf16* __restrict__ H, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, const float* __restrict__ sums,
-                                                         float invNp, long long rows, int C, int tpr) {
+                                                         float invNp, long long rows, int C, int tpr,
+                                                         __bf16* __restrict__ gsum = nullptr, int k = 1) {
     const int tc = threadIdx.x % tpr, tr = threadIdx.x / tpr, rpp = 256 / tpr;
     const int c = (blockIdx.x * tpr + tc) * 8;
     float sc[8], sh[8], a[8], b[8];          // BWD: dH = sc*dy*mask - a - b*h  with a = sc*(m1 - mu*is*m2), b = sc*is*m2
@@ -277,7 +282,11 @@ __global__ __launch_bounds__(256) void bn_colwise_kernel(const __bf16* __restric
         }
     }
     const long long r0 = (long long)blockIdx.y * BNC_ROWS, r1 = r0 + BNC_ROWS < rows ? r0 + BNC_ROWS : rows;
-    for (long long r = r0 + tr; r < r1; r += rpp) {
+    const int run = BNC_ROWS / rpp;                                   // GSUM: rows per thread, a multiple of k
+    float gs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int inrun = 0;
+    for (long long r = GSUM ? r0 + (long long)tr * run : r0 + tr; r < (GSUM ? (r0 + (long long)(tr + 1) * run < r1 ? r0 + (long long)(tr + 1) * run : r1) : r1);
+         r += GSUM ? 1 : rpp) {
         const size_t o = (size_t)r * C + c;
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + o);
         bf16x8 out;
@@ -294,6 +303,17 @@ __global__ __launch_bounds__(256) void bn_colwise_kernel(const __bf16* __restric
             for (int i = 0; i < 8; ++i) out[i] = f2bf(fmaxf(sc[i] * bf2f(v[i]) + sh[i], 0.f));
         }
         *reinterpret_cast<bf16x8*>(y + o) = out;
+        if (GSUM) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gs[i] += bf2f(out[i]);
+            if (++inrun == k) {
+                bf16x8 g8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { g8[i] = f2bf(gs[i]); gs[i] = 0.f; }
+                *reinterpret_cast<bf16x8*>(gsum + (size_t)(r / k) * C + c) = g8;
+                inrun = 0;
+            }
+        }
     }
 }
 
@@ -735,9 +755,24 @@ extern "C" int p4p_pool_bn_bwd(const void* dtok, int dtok_is_f32, const void* H3
     return 0;
 }
 
-// dY [rows,C] bf16 is overwritten with the gradient w.r.t. the BN input; sums[2][C] <- sum dy, sum dy*xhat
+extern "C" int p4p_group_sum_bf16(const void* X, void* out, long long G, int k, int C, void* stream);
+// dY [rows,C] bf16 is overwritten with the gradient w.r.t. the BN input; sums[2][C] <- sum dy, sum dy*xhat.
+// p4p_relu_bn_bwd_gsum additionally writes group_out [rows / k, C] bf16 = the sum of every k consecutive rows of the result (what
+// p4p_group_sum_bf16 computes from the finished tensor, bit for bit) -- from the same pass where the shape allows, else by that kernel.
+static int relu_bn_bwd_impl(void* dY, const void* H, const float* scale, const float* shift, const float* mean,
+                            const float* invstd, float* partial, float* sums, void* group_out, int k, long long rows, int C, void* stream);
 extern "C" int p4p_relu_bn_bwd(void* dY, const void* H, const float* scale, const float* shift, const float* mean,
                                const float* invstd, float* partial, float* sums, long long rows, int C, void* stream) {
+    return relu_bn_bwd_impl(dY, H, scale, shift, mean, invstd, partial, sums, nullptr, 1, rows, C, stream);
+}
+extern "C" int p4p_relu_bn_bwd_gsum(void* dY, const void* H, const float* scale, const float* shift, const float* mean,
+                                    const float* invstd, float* partial, float* sums, void* group_out, int k, long long rows, int C,
+                                    void* stream) {
+    P4P_CHECK(group_out && k >= 1 && rows % k == 0, "p4p_relu_bn_bwd_gsum: group_out / k (rows=%lld, k=%d)", rows, k);
+    return relu_bn_bwd_impl(dY, H, scale, shift, mean, invstd, partial, sums, group_out, k, rows, C, stream);
+}
+static int relu_bn_bwd_impl(void* dY, const void* H, const float* scale, const float* shift, const float* mean,
+                            const float* invstd, float* partial, float* sums, void* group_out, int k, long long rows, int C, void* stream) {
     P4P_CHECK(dY && H && scale && shift && mean && invstd && partial && sums, "p4p_relu_bn_bwd: null pointer");
     P4P_CHECK(rows >= 1 && C % 4 == 0, "p4p_relu_bn_bwd: bad sizes");
     hipStream_t st = (hipStream_t)stream;
@@ -749,15 +784,24 @@ extern "C" int p4p_relu_bn_bwd(void* dY, const void* H, const float* scale, cons
     P4P_LAUNCH_CHECK();
     if (p4p_colreduce_f32(partial, sums, nb, (long long)2 * C, 2 * C, 0.f, stream)) return 2;
     long long n = rows * C;
+    bool fused_gsum = false;
     if (C % 8 == 0) {
         const int tpr = bnc_tpr(C);
-        hipLaunchKernelGGL(bn_colwise_kernel<true>, dim3(C / 8 / tpr, ceil_div(rows, BNC_ROWS)), dim3(256), 0, st,
-                           (const __bf16*)dY, (__bf16*)dY, (const __bf16*)H, scale, shift, mean, invstd, sums,
-                           (float)(1.0 / (double)rows), rows, C, tpr);
+        const int run = BNC_ROWS / (256 / tpr);                      // rows a thread walks in the group-sum form
+        if (group_out && run % k == 0) {
+            fused_gsum = true;
+            hipLaunchKernelGGL((bn_colwise_kernel<true, true>), dim3(C / 8 / tpr, ceil_div(rows, BNC_ROWS)), dim3(256), 0, st,
+                               (const __bf16*)dY, (__bf16*)dY, (const __bf16*)H, scale, shift, mean, invstd, sums,
+                               (float)(1.0 / (double)rows), rows, C, tpr, (__bf16*)group_out, k);
+        } else
+            hipLaunchKernelGGL(bn_colwise_kernel<true>, dim3(C / 8 / tpr, ceil_div(rows, BNC_ROWS)), dim3(256), 0, st,
+                               (const __bf16*)dY, (__bf16*)dY, (const __bf16*)H, scale, shift, mean, invstd, sums,
+                               (float)(1.0 / (double)rows), rows, C, tpr, (__bf16*)nullptr, 1);
     } else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ceil_div(n / 4, 256)), dim3(256), 0, st, (__bf16*)dY,
                            (const __bf16*)H, scale, shift, mean, invstd, sums, (float)(1.0 / (double)rows), n, C);
     P4P_LAUNCH_CHECK();
+    if (group_out && !fused_gsum) return p4p_group_sum_bf16(dY, group_out, rows / k, k, C, stream);
     return 0;
 }
 

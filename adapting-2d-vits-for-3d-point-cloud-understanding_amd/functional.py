@@ -165,10 +165,9 @@ class _P3EmbedFn(torch.autograd.Function):
         dH3, s3 = ops.pool_bn_bwd(dtok, H3, arg3, sc3, sh3, mean3, is3, G, k)
         dW4 = ops.gemm_wgrad(dH3, F2)
         dF2 = ops.gemm_tn(dH3, W4T, ops.EPI_BF16)
-        s2 = ops.relu_bn_bwd_(dF2, H2, sc2, sh2, mean2, is2)          # dF2 now holds dH2
+        s2, dU = ops.relu_bn_bwd_(dF2, H2, sc2, sh2, mean2, is2, group=k)   # dF2 now holds dH2; dU = its sums over the k neighbours
         dW3b = ops.gemm_wgrad(dF2, F1)
         dF1 = ops.gemm_tn(dF2, W3bT, ops.EPI_BF16)
-        dU = ops.group_sum(dF2, G, k)
         dW3a = ops.gemm_wgrad(dU, pooled)
         dPooled = ops.gemm_tn(dU, W3aT, ops.EPI_BF16)
         dW1, dW2, db2, dg1, db1 = ops.embed_stage1_bwd(points, feats, idx, F1, dF1, dPooled, arg1, mom, aeff,

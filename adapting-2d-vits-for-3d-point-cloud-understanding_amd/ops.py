@@ -458,10 +458,17 @@ def pool_bn_bwd(dtok, H3, arg, scale, shift, mean, invstd, G, k):
     return dH3, sums
 
 
-def relu_bn_bwd_(dY, H, scale, shift, mean, invstd):
+def relu_bn_bwd_(dY, H, scale, shift, mean, invstd, group=None):
+    """dY <- gradient w.r.t. the BatchNorm input (in place); returns sums [2][C]; with group = k also the sums of every k consecutive
+    rows of the result ([rows / k, C] bf16: group_sum(dY, rows // k, k) out of the same pass)."""
     rows, C = H.shape
     part = _workspace('embed_part', embed_partial_rows() * 7 * 512, H.device)
     sums = torch.empty(2, C, dtype=torch.float32, device=H.device)
+    if group:
+        gs = torch.empty(rows // group, C, dtype=torch.bfloat16, device=H.device)
+        L.call('p4p_relu_bn_bwd_gsum', L.ptr(dY), L.ptr(H), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.ptr(part),
+               L.ptr(sums), L.ptr(gs), int(group), rows, C, _stream())
+        return sums, gs
     L.call('p4p_relu_bn_bwd', L.ptr(dY), L.ptr(H), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.ptr(part),
            L.ptr(sums), L.i64(rows), C, _stream())
     return sums

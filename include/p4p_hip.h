@@ -176,6 +176,10 @@ int p4p_pool_bn_bwd(const void* dtok, int dtok_is_f32, const void* H3, const uin
 /* backward of ReLU + BatchNorm on a dense gradient, in place over dY; sums as above */
 int p4p_relu_bn_bwd(void* dY, const void* H, const float* scale, const float* shift, const float* mean,
                     const float* invstd, float* partial, float* sums, long long rows, int C, void* stream);
+/* the same, and group_out [rows / k, C] bf16 = p4p_group_sum_bf16 of the result (bit for bit) out of the same pass (round 5) */
+int p4p_relu_bn_bwd_gsum(void* dY, const void* H, const float* scale, const float* shift, const float* mean,
+                         const float* invstd, float* partial, float* sums, void* group_out, int k, long long rows, int C,
+                         void* stream);
 int p4p_group_sum_bf16(const void* X, void* out, long long G, int k, int C, void* stream);
 /* backward of stage 1 (ReLU, BatchNorm, both leading convs) in closed form from sum(dy), sum(dy (x) x6) */
 int p4p_embed_stage1_bwd(const float* points, const float* feats, const int32_t* idx, const void* F1, const void* dF1,
