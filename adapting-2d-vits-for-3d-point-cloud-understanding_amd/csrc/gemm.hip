@@ -29,6 +29,8 @@ __device__ float g_zero_page[64];   // 256 B of zeros: LDS-DMA source for rows p
 #include "gemm_tn4.h"
 #include "gemm_tn4p.h"
 #include "gemm_wgrad3.h"
+#include "gemm_wgrad4.h"
+#include "gemm_wgrad5.h"
 
 #define GEMM_THREADS 256
 
@@ -530,9 +532,10 @@ extern "C" int p4p_sum_slabs_multi(const void* descs, int n, void* stream) {
 }
 
 static bool wgrad_use_v3(int M, int N, int K) { return N % W3_BN == 0 && K % W3_BK == 0 && M >= 4096; }
-static int g_wgrad_wide = 2;      // 0: 256x128 tiles, 1: 256x256, 2: 256x256 with the hand-interleaved issue order
+static int g_wgrad_wide = 2;      // 0: 256x128 tiles, 1: 256x256, 2 (default): 256x256 with the hand-interleaved issue order, 3 (opt-in, measured slower: NOTES R5.6): 256x256 on the staggered 4-phase schedule (gemm_wgrad4.h) where K % 256 == 0, else as 2
 extern "C" int p4p_set_wgrad_wide(int v) { int o = g_wgrad_wide; g_wgrad_wide = v; return o; }
 static bool wgrad3_wide(int K) { return (g_wgrad_wide & 3) && K % 256 == 0; }      // 256x256 tile, 8 waves, 1 workgroup per CU
+static bool wgrad_use_v4(int M, int N, int K) { return (g_wgrad_wide & 3) == 3 && wgrad_use_v3(M, N, K) && N % 256 == 0 && K % 256 == 0; }
 static int wgrad3_steps_per_split(int M, int N, int K) {
     // one round of workgroups: as many M-splits as the resident slots allow -- the CUs p4p_set_reserved_cus() leaves (capi.cpp):
     // with r CUs held by another kernel a grid of 256 would run 256 - r workgroups and then r more, i.e. take twice as long
@@ -545,12 +548,25 @@ static int wgrad3_steps_per_split(int M, int N, int K) {
     if (want > steps) want = steps;
     return ceil_div(steps, want);
 }
+static int wgrad4_tiles_per_split(int M, int N, int K) {      // the same rule in units of gemm_wgrad4.h's 64-row contraction tiles
+    const int pg = p4p_persistent_grid(), cus = pg > 0 ? pg : 256;
+    const int tiles = (N / 256) * (K / 256), steps = ceil_div(M, 64);
+    int want = cus / tiles;
+    if (want < 1) want = 1;
+    if (want > steps) want = steps;
+    return ceil_div(steps, want);
+}
+// M-splits (= slabs) of the ring kernels for this shape under the current switches
+static int wgrad_ring_splits(int M, int N, int K) {
+    if (wgrad_use_v4(M, N, K)) return ceil_div(ceil_div(M, 64), wgrad4_tiles_per_split(M, N, K));
+    return ceil_div(ceil_div(M, 32), wgrad3_steps_per_split(M, N, K));
+}
 
 extern "C" int p4p_colsum_bf16(const void* G, float* out, float* workspace, int M, int N, float beta, void* stream);
 
 extern "C" int p4p_wgrad_splits(int M, int N, int K) {
     // the ring kernel keeps the column-sum partials (<= 256 rows of N floats) behind its slabs: +2 slabs (K >= 128) cover them
-    if (wgrad_use_v3(M, N, K)) return ceil_div(ceil_div(M, 32), wgrad3_steps_per_split(M, N, K)) + 2;
+    if (wgrad_use_v3(M, N, K)) return wgrad_ring_splits(M, N, K) + 2;
     int tiles = ceil_div(N, 128) * ceil_div(K, 128);
     int chunks = ceil_div(M, WG_BMR);
     int want = ceil_div(1024, tiles);             // ~4 workgroups per CU over the whole grid
@@ -563,16 +579,33 @@ extern "C" int p4p_wgrad_splits(int M, int N, int K) {
 // the GEMM of p4p_gemm_wgrad_bf16 WITHOUT its slab sum (ring kernel shapes only): slabs [p4p_wgrad_slab_count(M,N,K)][N][K] are left
 // in `workspace` for a later p4p_sum_slabs_multi.  p4p_wgrad_slab_count returns 0 for shapes the ring kernel does not take.
 extern "C" int p4p_wgrad_slab_count(int M, int N, int K) {
-    return wgrad_use_v3(M, N, K) ? ceil_div(ceil_div(M, 32), wgrad3_steps_per_split(M, N, K)) : 0;
+    return wgrad_use_v3(M, N, K) ? wgrad_ring_splits(M, N, K) : 0;
 }
 static int launch_wgrad3(const void* G, const void* A, float* workspace, int M, int N, int K, hipStream_t st, int* splits_out) {
+    if (wgrad_use_v4(M, N, K)) {
+        W4Params q;
+        q.G = (const __bf16*)G; q.A = (const __bf16*)A; q.M = M; q.N = N; q.K = K; q.out = workspace;
+        q.tiles_per_split = wgrad4_tiles_per_split(M, N, K);
+        const int splits4 = ceil_div(ceil_div(M, 64), q.tiles_per_split);
+        P4P_CHECK((unsigned long long)64 * (N > K ? N : K) * 2 < (1ull << 31), "p4p_gemm_wgrad_bf16: row stride too large");
+        const bool prof = p4p_prof_begin(1, 2.0 * M * N * K, st);
+        hipLaunchKernelGGL(gemm_wgrad4_kernel, dim3((N / 256) * (K / 256) * splits4), dim3(512), 0, st, q);
+        if (prof) p4p_prof_end(st);
+        P4P_LAUNCH_CHECK();
+        *splits_out = splits4;
+        return 0;
+    }
     W3Params q;
     q.G = (const __bf16*)G; q.A = (const __bf16*)A; q.M = M; q.N = N; q.K = K;
     q.steps_per_split = wgrad3_steps_per_split(M, N, K);
     const int splits3 = ceil_div(ceil_div(M, 32), q.steps_per_split);
     q.out = workspace;
     const bool prof = p4p_prof_begin(1, 2.0 * M * N * K, st);
-    if (wgrad3_wide(K) && (g_wgrad_wide & 3) == 2)
+    if (wgrad3_wide(K) && (g_wgrad_wide & 12) == 4)          // bit 2: four waves of 128 x 128 (gemm_wgrad5.h), hand-interleaved
+        hipLaunchKernelGGL((gemm_wgrad5_kernel<true>), dim3((N / W3_BN) * (K / 256) * splits3), dim3(256), 0, st, q);
+    else if (wgrad3_wide(K) && (g_wgrad_wide & 12) == 8)     // bit 3: the same, compiler-scheduled
+        hipLaunchKernelGGL((gemm_wgrad5_kernel<false>), dim3((N / W3_BN) * (K / 256) * splits3), dim3(256), 0, st, q);
+    else if (wgrad3_wide(K) && (g_wgrad_wide & 3) >= 2)
         hipLaunchKernelGGL((gemm_wgrad3_kernel<256, true>), dim3((N / W3_BN) * (K / 256) * splits3), dim3(512), 0, st, q);
     else if (wgrad3_wide(K))
         hipLaunchKernelGGL(gemm_wgrad3_kernel<256>, dim3((N / W3_BN) * (K / 256) * splits3), dim3(512), 0, st, q);

@@ -777,19 +777,27 @@ def test_attention_backward_is_bitwise_reproducible_under_load(B, T, runs):
         assert torch.equal(cs, ref_cs), f'column sums differ in run {r}'
 
 
-@pytest.mark.parametrize('M,N,K', [(4096, 256, 128), (5000, 768, 768), (4099, 512, 256), (65792, 768, 256)])
-def test_gemm_wgrad_ring_kernel_exact_on_integer_data(M, N, K):
-    """Shapes that take the 256x128 ring kernel (N%256==0, K%128==0, M>=4096), incl. a ragged M tail."""
+# weight-gradient kernels behind p4p_set_wgrad_wide: 2 = gemm_wgrad3.h (8 waves of 128 x 64, the default), 3 = gemm_wgrad4.h (the staggered
+# 4-phase schedule), 6 / 10 = gemm_wgrad5.h (4 waves of 128 x 128, hand-interleaved / compiler-scheduled); where K % 256 != 0 all fall back to 2
+@pytest.mark.parametrize('variant', [2, 3, 6, 10])
+@pytest.mark.parametrize('M,N,K', [(4096, 256, 128), (5000, 768, 768), (4099, 512, 256), (65792, 768, 256), (4160, 256, 256), (8191, 768, 3072)])
+def test_gemm_wgrad_ring_kernel_exact_on_integer_data(M, N, K, variant):
+    """Shapes that take the ring kernels (N%256==0, K%128==0, M>=4096), incl. ragged M tails (M % 64 = 8, 3, 63) and M % 64 = 0."""
+    from p4p_amd import _lib
     g = _int_bf16((M, N), -1, 1, 5).to(DEV)
     a = _int_bf16((M, K), -2, 2, 6).to(DEV)
     if M > 20000:
         g = (g * (torch.rand(M, N, device=DEV) < 0.05)).to(torch.bfloat16).contiguous()   # keep sums exact in fp32
     want = g.float().t() @ a.float()
-    dw, db = ops.gemm_wgrad(g, a, want_bias=True)
-    assert torch.equal(dw, want)
-    assert torch.equal(db, g.float().sum(0))
-    acc = ops.gemm_wgrad(g, a, out=dw.clone(), beta=1.0)
-    assert torch.equal(acc, 2 * want)
+    old = _lib.call_int('p4p_set_wgrad_wide', variant)
+    try:
+        dw, db = ops.gemm_wgrad(g, a, want_bias=True)
+        assert torch.equal(dw, want)
+        assert torch.equal(db, g.float().sum(0))
+        acc = ops.gemm_wgrad(g, a, out=dw.clone(), beta=1.0)
+        assert torch.equal(acc, 2 * want)
+    finally:
+        _lib.call_int('p4p_set_wgrad_wide', old)
 
 
 def test_gemm_wgrad_deferred_slab_sums_are_one_launch_and_bit_identical():
@@ -818,8 +826,9 @@ def test_gemm_wgrad_deferred_slab_sums_are_one_launch_and_bit_identical():
             assert torch.equal(x, y), (N, K, beta)
 
 
-@pytest.mark.parametrize('M,N,K', [(11009, 768, 256), (4099, 3072, 1024), (32771, 512, 128)])
-def test_gemm_wgrad_ring_kernel_never_reads_past_a_ragged_end(M, N, K):
+@pytest.mark.parametrize('variant', [2, 3, 6])
+@pytest.mark.parametrize('M,N,K', [(11009, 768, 256), (4099, 3072, 1024), (32771, 512, 128), (16392, 1024, 1024)])
+def test_gemm_wgrad_ring_kernel_never_reads_past_a_ragged_end(M, N, K, variant):
     """Regression (round 2): with an ODD number (>= 5) of 32-row steps in the last M-split and M % 32 != 0 the unchecked
     fast staging path of gemm_wgrad3_kernel fetched the ragged last step, i.e. up to 31 rows past the end of both
     operands (first seen as a run-to-run difference of the ViT-L / N=8192 weight gradients, M = 16392).  The operands
@@ -830,7 +839,12 @@ def test_gemm_wgrad_ring_kernel_never_reads_past_a_ragged_end(M, N, K):
     af[:M] = _int_bf16((M, K), -2, 2, 6).to(DEV)
     g, a = gf[:M], af[:M]
     assert g.is_contiguous() and a.is_contiguous()
-    dw = ops.gemm_wgrad(g, a)
+    from p4p_amd import _lib
+    old = _lib.call_int('p4p_set_wgrad_wide', variant)
+    try:
+        dw = ops.gemm_wgrad(g, a)
+    finally:
+        _lib.call_int('p4p_set_wgrad_wide', old)
     assert torch.equal(dw, g.float().t() @ a.float())
 
 

@@ -15,12 +15,12 @@ for name, (n, k) in shapes.items():
     dw = torch.empty(n, k, device='cuda')
     res, ref = {}, None
     for rnd in range(3):
-        for v in (1, 2):                  # 256x256 tile without / with the hand-interleaved issue order
+        for v in (2, 3, 6, 10):           # gemm_wgrad3.h (hand-interleaved ring) / gemm_wgrad4.h (staggered 4-phase schedule) / gemm_wgrad5.h (4 waves of 128 x 128: hand-interleaved, compiler-scheduled)
             lib.p4p_set_wgrad_wide(v)
             ops.gemm_wgrad(G, A, out=dw); torch.cuda.synchronize()
-            if rnd == 0:
+            if rnd == 0:                   # different M-splits, different summation order: close, not equal
                 if ref is None: ref = dw.clone()
-                else: assert torch.equal(ref, dw), name
+                else: assert (ref - dw).abs().max().item() <= 2e-4 * ref.abs().max().item(), (name, (ref - dw).abs().max().item())
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             for _ in range(10): ops.gemm_wgrad(G, A, out=dw)
