@@ -201,7 +201,7 @@ int p4p_stream_destroy(void* stream);
 int p4p_device_cu_count(void);
 /* experiment switches (tools/gemm_bench.py): tile configuration overrides, 0 = automatic */
 int p4p_set_gemm_variant(int v);
-int p4p_set_wgrad_wide(int v);
+int p4p_set_wgrad_wide(int v);             /* weight-gradient GEMM where K % 256 == 0: 2 (default) gemm_wgrad3.h, 8 waves of 128 x 64, hand-interleaved; 3 gemm_wgrad4.h, the staggered 4-phase schedule (12 % slower); 6 / 10 gemm_wgrad5.h, 4 waves of 128 x 128 with AGPR accumulators, hand-interleaved / compiler-scheduled (bit-identical to 2; +1-3 % per kernel, nothing per step); 0 / 1: 256 x 128 tiles / 256 x 256 compiler-scheduled */
 int p4p_set_gemm_persistent(int v);        /* 1 (default): short-K GEMMs with several tiles per CU run the persistent tile loop (gemm_tn4p.h); 0: one workgroup per tile; 3: persistent without the banded tile order of wide outputs */
 int p4p_set_gemm_epilogue(int v);          /* bit 1: no start-time shift in the persistent GEMM; bits 8..: that shift in 1,024-cycle units (0 = the per-epilogue default); bit 0: unused */
 int p4p_set_gemm_peel_rounds(int v);       /* wide outputs (> 4 tiles of 256 columns): peel the tail row panel(s) into a small-tile launch when the big tiles run at most v rounds (default 4; 32 was measured faster per kernel and slower per step: NOTES A.8) */
