@@ -43,9 +43,19 @@ def wgrad_case():
     K = int(rng.choice([8 * logint(1, 96), 256 * logint(1, 4)]))
     g, a = ints((M, N), -1, 1), ints((M, K), -2, 2)
     want = g.float().t() @ a.float()
-    assert torch.equal(ops.gemm_wgrad(g, a), want), ('wgrad', M, N, K)
-    dw, db = ops.gemm_wgrad(g, a, want_bias=True)
-    assert torch.equal(dw, want) and torch.equal(db, g.float().sum(0)), ('wgrad+bias', M, N, K)
+    from p4p_amd import _lib
+    variant = int(rng.choice([2, 3, 6, 10]))          # gemm_wgrad3.h / gemm_wgrad4.h / gemm_wgrad5.h (round 5), where the shape takes them
+    old = _lib.call_int('p4p_set_wgrad_wide', variant)
+    try:
+        assert torch.equal(ops.gemm_wgrad(g, a), want), ('wgrad', M, N, K, variant)
+        dw, db = ops.gemm_wgrad(g, a, want_bias=True)
+        assert torch.equal(dw, want) and torch.equal(db, g.float().sum(0)), ('wgrad+bias', M, N, K, variant)
+        queue = []                                     # the deferred slab sum (round 5): same bits after the flush
+        dq = ops.gemm_wgrad(g, a, defer=queue)
+        ops.wgrad_flush(queue)
+        assert torch.equal(dq, want), ('wgrad deferred', M, N, K, variant)
+    finally:
+        _lib.call_int('p4p_set_wgrad_wide', old)
     return ('wgrad', M, N, K)
 
 
