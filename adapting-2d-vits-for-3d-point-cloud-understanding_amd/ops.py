@@ -129,10 +129,14 @@ _wgrad_ws = {}
 
 
 def _workspace(key, numel, device, dtype=torch.float32):
-    t = _wgrad_ws.get((key, device, dtype))
+    """A persistent scratch buffer per (purpose, device, dtype, STREAM): kernels of one stream run in order, so reusing the buffer
+    behind the previous call on that stream is safe; two streams never share one (the buffers used to be keyed
+    without the stream).  A buffer that grows is replaced; the old one is freed by torch's stream-ordered allocator."""
+    k = (key, device, dtype, _stream().value)
+    t = _wgrad_ws.get(k)
     if t is None or t.numel() < numel:
         t = torch.empty(int(numel), dtype=dtype, device=device)
-        _wgrad_ws[(key, device, dtype)] = t
+        _wgrad_ws[k] = t
     return t
 
 

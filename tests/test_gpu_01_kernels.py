@@ -580,7 +580,7 @@ def test_attention_backward_t513_workspace_belongs_to_the_call():
         do = torch.randn(B * T, D, device=DEV, generator=g).bfloat16()
         o, lse = ops.attention_fwd(qkv, B, T, H)
         ins.append((qkv, o, do, lse))
-    want = [ops.attention_bwd(q, o, do, lse, B, T, H).clone() for q, o, do, lse in ins]
+    want = [tuple(x.clone() for x in ops.attention_bwd(q, o, do, lse, B, T, H, want_colsum=True)) for q, o, do, lse in ins]
     torch.cuda.synchronize()
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     got = [[], []]
@@ -588,11 +588,13 @@ def test_attention_backward_t513_workspace_belongs_to_the_call():
         for i, st in enumerate(streams):
             with torch.cuda.stream(st):
                 q, o, do, lse = ins[i]
-                got[i].append(ops.attention_bwd(q, o, do, lse, B, T, H))
+                # the column-sum partials go through ops._workspace: a buffer per (purpose, device, dtype, stream)
+                got[i].append(ops.attention_bwd(q, o, do, lse, B, T, H, want_colsum=True))
     torch.cuda.synchronize()
     for i in range(2):
-        for rep, x in enumerate(got[i]):
-            assert torch.equal(x, want[i]), f'stream {i}, launch {rep}: a concurrent call disturbed the parked dQ chains'
+        for rep, (x, cs) in enumerate(got[i]):
+            assert torch.equal(x, want[i][0]), f'stream {i}, launch {rep}: a concurrent call disturbed the parked dQ chains'
+            assert torch.equal(cs, want[i][1]), f'stream {i}, launch {rep}: a concurrent call disturbed the column-sum partials'
 
 
 @pytest.mark.parametrize('B,T,H', [(2, 2049, 3), (1, 1300, 2), (3, 513, 4)])
